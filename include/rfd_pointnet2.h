@@ -1,0 +1,136 @@
+/*
+ * rfd_pointnet2.h -- C ABI of the MI355X (gfx950) PointNet++ operator library
+ * (librfd_hip.so).  Drop-in boundary for RfD-Net's `pointnet2_ops._ext`.
+ *
+ * Every entry point below replaces one `*_kernel_wrapper` that the reference's
+ * C++ host layer declares and its .cu files define:
+ *
+ *   reference declaration (external/pointnet2_ops_lib/pointnet2_ops/_ext-src/)
+ *   ----------------------------------------------------------------------------
+ *   src/sampling.cpp:4-13      gather_points[_grad]_kernel_wrapper,
+ *                              furthest_point_sampling_kernel_wrapper
+ *   src/ball_query.cpp:4-6     query_ball_point_kernel_wrapper
+ *   src/group_points.cpp:4-10  group_points[_grad]_kernel_wrapper
+ *   src/interpolate.cpp:4-12   three_nn / three_interpolate[_grad]_kernel_wrapper
+ *
+ * Same names, argument order and meaning; the ONE addition is a trailing
+ * `void* stream` (a hipStream_t; NULL = the default stream) because the
+ * reference fetches `at::cuda::getCurrentCUDAStream()` implicitly
+ * (sampling_gpu.cu:26,180) and a C ABI cannot.  All launches are asynchronous
+ * on that stream; nothing here synchronises or allocates per call (a small
+ * per-device workspace for the multi-workgroup FPS exchange is allocated once,
+ * lazily).  Pointers are device pointers on the CURRENT HIP device; layouts are
+ * dense row-major exactly as in the reference (CHECK_CONTIGUOUS, utils.h:10-13).
+ *
+ * Error behaviour: the reference prints and exit(-1)s on a launch failure
+ * (cuda_utils.h:30-39).  Here every function returns 0 on success or a
+ * hipError_t value; rfd_last_error_string() describes the last failure of the
+ * calling thread.  Callers raise instead of exiting.
+ *
+ * Differences the caller may rely on (supersets of the reference contract):
+ *   - query_ball_point writes EVERY element of idx (rows without a neighbour
+ *     are written as zeros), so idx need not be pre-zeroed (the reference host
+ *     zero-fills it, ball_query.cpp:19-21; pre-zeroing remains harmless).
+ *   - furthest_point_sampling requires `temp` (b*n floats) like the reference
+ *     and leaves in it the same final min-distances the CUDA kernel leaves;
+ *     it need not be pre-filled with 1e10 (sampling.cpp:74-76) -- the kernel
+ *     initialises it.
+ */
+#ifndef RFD_POINTNET2_H
+#define RFD_POINTNET2_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sampling.cpp:11-13 / sampling_gpu.cu:176-229.
+ * dataset (b,n,3) f32, temp (b,n) f32 scratch, idxs (b,m) i32 out. */
+int furthest_point_sampling_kernel_wrapper(int b, int n, int m,
+                                           const float *dataset, float *temp,
+                                           int *idxs, void *stream);
+
+/* sampling.cpp:4-6 / sampling_gpu.cu:22-30.
+ * points (b,c,n) f32, idx (b,npoints) i32, out (b,c,npoints) f32. */
+int gather_points_kernel_wrapper(int b, int c, int n, int npoints,
+                                 const float *points, const int *idx,
+                                 float *out, void *stream);
+
+/* sampling.cpp:7-9 / sampling_gpu.cu:49-57.  grad_points (b,c,n) must be
+ * zero-initialised by the caller (sampling.cpp:49-51); scatter-add. */
+int gather_points_grad_kernel_wrapper(int b, int c, int n, int npoints,
+                                      const float *grad_out, const int *idx,
+                                      float *grad_points, void *stream);
+
+/* ball_query.cpp:4-6 / ball_query_gpu.cu:46-54.
+ * new_xyz (b,m,3), xyz (b,n,3) f32, idx (b,m,nsample) i32 out. */
+int query_ball_point_kernel_wrapper(int b, int n, int m, float radius,
+                                    int nsample, const float *new_xyz,
+                                    const float *xyz, int *idx, void *stream);
+
+/* group_points.cpp:4-6 / group_points_gpu.cu:30-38.
+ * points (b,c,n) f32, idx (b,npoints,nsample) i32, out (b,c,npoints,nsample). */
+int group_points_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                const float *points, const int *idx,
+                                float *out, void *stream);
+
+/* group_points.cpp:8-10 / group_points_gpu.cu:66-75.  grad_points (b,c,n)
+ * zero-initialised by the caller (group_points.cpp:48-50). */
+int group_points_grad_kernel_wrapper(int b, int c, int n, int npoints,
+                                     int nsample, const float *grad_out,
+                                     const int *idx, float *grad_points,
+                                     void *stream);
+
+/* interpolate.cpp:4-5 / interpolate_gpu.cu:61-68.
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) SQUARED, idx (b,n,3). */
+int three_nn_kernel_wrapper(int b, int n, int m, const float *unknown,
+                            const float *known, float *dist2, int *idx,
+                            void *stream);
+
+/* interpolate.cpp:6-8 / interpolate_gpu.cu:103-111.
+ * points (b,c,m), idx/weight (b,n,3) -> out (b,c,n). */
+int three_interpolate_kernel_wrapper(int b, int c, int m, int n,
+                                     const float *points, const int *idx,
+                                     const float *weight, float *out,
+                                     void *stream);
+
+/* interpolate.cpp:9-12 / interpolate_gpu.cu:145-154.  grad_points (b,c,m)
+ * zero-initialised by the caller (interpolate.cpp:85-87). */
+int three_interpolate_grad_kernel_wrapper(int b, int c, int n, int m,
+                                          const float *grad_out,
+                                          const int *idx, const float *weight,
+                                          float *grad_points, void *stream);
+
+/* ---- fused forms (no reference counterpart; used by the host mirror of
+ * QueryAndGroup, pointnet2_utils.py:302-361, to avoid materialising and
+ * re-reading the grouped tensor).  Results are bit-identical to composing the
+ * reference ops: group(xyz^T, idx) - centre [ / radius ] and group(features). */
+
+/* out (b, 3+c, m, nsample): channels 0..2 = (xyz[idx] - new_xyz) [/ radius if
+ * normalize], channels 3.. = features[:, idx].  features may be NULL (c = 0).
+ * If grouped_xyz_out != NULL it receives channels 0..2 as (b,3,m,nsample).
+ * xyz (b,n,3), new_xyz (b,m,3), features (b,c,n), idx (b,m,nsample). */
+int rfd_group_concat(int b, int c, int n, int m, int nsample, float radius,
+                     int normalize, int use_xyz, const float *xyz,
+                     const float *new_xyz, const float *features,
+                     const int *idx, float *out, float *grouped_xyz_out,
+                     void *stream);
+
+/* FPS that also emits the sampled centres: new_xyz (b,m,3) = dataset[idxs]
+ * (== gather_points(dataset^T, idxs)^T, pointnet2_modules.py:224-226). */
+int rfd_furthest_point_sampling_gather(int b, int n, int m,
+                                       const float *dataset, float *temp,
+                                       int *idxs, float *new_xyz,
+                                       void *stream);
+
+/* ---- diagnostics --------------------------------------------------------- */
+const char *rfd_last_error_string(void);
+/* Device-side status word of the persistent kernels (FPS exchange spin
+ * limit).  Synchronises the device.  0 = OK. */
+int rfd_device_status(void);
+/* "gfx950" etc. of the code object actually loaded. */
+const char *rfd_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFD_POINTNET2_H */

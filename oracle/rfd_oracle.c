@@ -1,0 +1,682 @@
+/*
+ * rfd_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the reference algorithms on RfD-Net's hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.  The
+ * product (rfdnet_amd/) never links, imports or calls it.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout root).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - point ops (FPS, gather, ball_query, group, three_nn, three_interpolate):
+ *     the reference holds NO golden vectors and its kernels are CUDA-only, so
+ *     these are "parity unpinned" against real CUDA output.  They are pinned by
+ *     (a) this statement-by-statement restatement, (b) an independent numpy
+ *     cross-check (tests/test_oracle_ops.py) and (c) fixtures captured by
+ *     running the reference's own Python modules (Pointnet2Backbone, SA/FP
+ *     modules) on top of this oracle (tests/golden/make_fixtures.py).
+ *   - occupancy decoder: pinned against the reference's DecoderCBatchNorm run
+ *     in-container (fixture F-DEC).
+ *   - MISE: pinned against the reference's mise.pyx compiled in-container
+ *     (fixture F-MISE, includes the external/libmise/test.py case).
+ *
+ * Floating-point contract.  The reference .cu files are built by nvcc with its
+ * default -fmad=true, which contracts a*a + b*b + c*c into
+ *     t = b*b;  t = fma(a,a,t);  t = fma(c,c,t)
+ * (first product fused into the add with the second, third fused last -- the
+ * same rule LLVM's DAG combiner applies).  No CUDA-produced golden exists, so
+ * this order is an ASSUMPTION, stated here once and used by both this oracle
+ * and the HIP kernels (explicit fmaf, contraction off in both builds).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ---- shared arithmetic helpers ------------------------------------------ */
+
+/* nvcc -fmad=true evaluation order of a*a + b*b + c*c (see header). */
+static inline float sumsq3(float a, float b, float c) {
+  float t = b * b;
+  t = fmaf(a, a, t);
+  t = fmaf(c, c, t);
+  return t;
+}
+
+/* cuda_utils.h:13-19 opt_n_threads */
+ORACLE_API int oracle_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int v = 1 << pow_2;
+  if (v > 512) v = 512;
+  if (v < 1) v = 1;
+  return v;
+}
+
+ORACLE_API int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+ORACLE_API void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+/* ---- A1: furthest point sampling ----------------------------------------
+ * sampling_gpu.cu:69-173 (kernel), sampling.cpp:66-87 (host: idxs zero-init,
+ * temp filled with 1e10).  The CUDA thread block is simulated literally:
+ * block_size = opt_n_threads(n) threads, thread `tid` visits k = tid, tid+BS,
+ * ..., the shared-memory tree (sampling_gpu.cu:59-65, 115-168) is replayed
+ * level by level so that ties resolve exactly as on the GPU.
+ * temp must be pre-filled by the caller (1e10) as the reference host does. */
+ORACLE_API void oracle_furthest_point_sampling(int b, int n, int m,
+                                               const float *dataset,
+                                               float *temp, int *idxs) {
+  if (m <= 0) return; /* sampling_gpu.cu:73 */
+  const int bs = oracle_opt_n_threads(n);
+  float *dists = (float *)malloc(sizeof(float) * bs);
+  int *dists_i = (int *)malloc(sizeof(int) * bs);
+  for (int bi = 0; bi < b; ++bi) {
+    const float *ds = dataset + (size_t)bi * n * 3;
+    float *tp = temp + (size_t)bi * n;
+    int *out = idxs + (size_t)bi * m;
+    int old = 0;
+    out[0] = old; /* :86-87 */
+    for (int j = 1; j < m; ++j) {
+      const float x1 = ds[old * 3 + 0], y1 = ds[old * 3 + 1],
+                  z1 = ds[old * 3 + 2];
+      for (int tid = 0; tid < bs; ++tid) {
+        int besti = 0;     /* :90 */
+        float best = -1.f; /* :91 */
+        for (int k = tid; k < n; k += bs) {
+          const float x2 = ds[k * 3 + 0], y2 = ds[k * 3 + 1],
+                      z2 = ds[k * 3 + 2];
+          const float mag = sumsq3(x2, y2, z2); /* :100 */
+          if ((double)mag <= 1e-3) continue;    /* :101 (double literal) */
+          const float d = sumsq3(x2 - x1, y2 - y1, z2 - z1); /* :103-104 */
+          const float d2 = fminf(d, tp[k]);                  /* :106 */
+          tp[k] = d2;
+          besti = d2 > best ? k : besti; /* :108 */
+          best = d2 > best ? d2 : best;  /* :109 */
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+      }
+      /* :115-168 tree reduction, __update keeps the left entry on ties */
+      for (int s = bs / 2; s >= 1; s >>= 1) {
+        for (int tid = 0; tid < s; ++tid) {
+          const float v1 = dists[tid], v2 = dists[tid + s];
+          const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+          dists[tid] = v1 > v2 ? v1 : v2; /* max(v1, v2) */
+          dists_i[tid] = v2 > v1 ? i2 : i1;
+        }
+      }
+      old = dists_i[0]; /* :170 */
+      out[j] = old;
+    }
+  }
+  free(dists);
+  free(dists_i);
+}
+
+/* ---- A2: gather_points -- sampling_gpu.cu:8-20 --------------------------- */
+ORACLE_API void oracle_gather_points(int b, int c, int n, int m,
+                                     const float *points, const int *idx,
+                                     float *out) {
+  for (int i = 0; i < b; ++i)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < m; ++j) {
+        const int a = idx[(size_t)i * m + j];
+        out[((size_t)i * c + l) * m + j] = points[((size_t)i * c + l) * n + a];
+      }
+}
+
+/* K3: gather_points_grad -- sampling_gpu.cu:34-47 (atomicAdd scatter) */
+ORACLE_API void oracle_gather_points_grad(int b, int c, int n, int m,
+                                          const float *grad_out,
+                                          const int *idx, float *grad_points) {
+  for (int i = 0; i < b; ++i)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < m; ++j) {
+        const int a = idx[(size_t)i * m + j];
+        grad_points[((size_t)i * c + l) * n + a] +=
+            grad_out[((size_t)i * c + l) * m + j];
+      }
+}
+
+/* ---- A3: ball query -- ball_query_gpu.cu:9-44 ----------------------------
+ * idx must be zero-initialised by the caller (ball_query.cpp:19-21): a centre
+ * with no neighbour keeps an all-zero row. */
+ORACLE_API void oracle_ball_query(int b, int n, int m, float radius,
+                                  int nsample, const float *new_xyz,
+                                  const float *xyz, int *idx) {
+  const float radius2 = radius * radius; /* :22 */
+  for (int bi = 0; bi < b; ++bi) {
+    const float *px = xyz + (size_t)bi * n * 3;
+    const float *pc = new_xyz + (size_t)bi * m * 3;
+    int *pi = idx + (size_t)bi * m * nsample;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int j = 0; j < m; ++j) {
+      const float new_x = pc[j * 3 + 0], new_y = pc[j * 3 + 1],
+                  new_z = pc[j * 3 + 2];
+      for (int k = 0, cnt = 0; k < n && cnt < nsample; ++k) { /* :27 */
+        const float x = px[k * 3 + 0], y = px[k * 3 + 1], z = px[k * 3 + 2];
+        const float d2 = sumsq3(new_x - x, new_y - y, new_z - z); /* :31-32 */
+        if (d2 < radius2) {                                       /* :33 */
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) pi[(size_t)j * nsample + l] = k;
+          pi[(size_t)j * nsample + cnt] = k;
+          ++cnt;
+        }
+      }
+    }
+  }
+}
+
+/* ---- A4: group_points -- group_points_gpu.cu:8-28 ------------------------ */
+ORACLE_API void oracle_group_points(int b, int c, int n, int npoints,
+                                    int nsample, const float *points,
+                                    const int *idx, float *out) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *pp = points + (size_t)bi * n * c;
+    const int *pi = idx + (size_t)bi * npoints * nsample;
+    float *po = out + (size_t)bi * npoints * nsample * c;
+#pragma omp parallel for
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < npoints; ++j)
+        for (int k = 0; k < nsample; ++k) {
+          const int ii = pi[(size_t)j * nsample + k];
+          po[((size_t)l * npoints + j) * nsample + k] = pp[(size_t)l * n + ii];
+        }
+  }
+}
+
+/* K6: group_points_grad -- group_points_gpu.cu:43-64 */
+ORACLE_API void oracle_group_points_grad(int b, int c, int n, int npoints,
+                                         int nsample, const float *grad_out,
+                                         const int *idx, float *grad_points) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *go = grad_out + (size_t)bi * npoints * nsample * c;
+    const int *pi = idx + (size_t)bi * npoints * nsample;
+    float *gp = grad_points + (size_t)bi * n * c;
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < npoints; ++j)
+        for (int k = 0; k < nsample; ++k) {
+          const int ii = pi[(size_t)j * nsample + k];
+          gp[(size_t)l * n + ii] += go[((size_t)l * npoints + j) * nsample + k];
+        }
+  }
+}
+
+/* ---- A5: three_nn -- interpolate_gpu.cu:9-59 ----------------------------
+ * best1..3 are doubles initialised to 1e40, d is computed in float; strict
+ * '<' cascade => lowest index wins ties.  Outputs SQUARED distances. */
+ORACLE_API void oracle_three_nn(int b, int n, int m, const float *unknown,
+                                const float *known, float *dist2, int *idx) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *pu = unknown + (size_t)bi * n * 3;
+    const float *pk = known + (size_t)bi * m * 3;
+    float *pd = dist2 + (size_t)bi * n * 3;
+    int *pi = idx + (size_t)bi * n * 3;
+#pragma omp parallel for
+    for (int j = 0; j < n; ++j) {
+      const float ux = pu[j * 3 + 0], uy = pu[j * 3 + 1], uz = pu[j * 3 + 2];
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        const float x = pk[k * 3 + 0], y = pk[k * 3 + 1], z = pk[k * 3 + 2];
+        const float d = sumsq3(ux - x, uy - y, uz - z); /* :33 */
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d;     besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d;     besti2 = k;
+        } else if (d < best3) {
+          best3 = d;     besti3 = k;
+        }
+      }
+      pd[j * 3 + 0] = (float)best1;
+      pd[j * 3 + 1] = (float)best2;
+      pd[j * 3 + 2] = (float)best3;
+      pi[j * 3 + 0] = besti1;
+      pi[j * 3 + 1] = besti2;
+      pi[j * 3 + 2] = besti3;
+    }
+  }
+}
+
+/* ---- A6: three_interpolate -- interpolate_gpu.cu:72-101 ------------------
+ * out = p1*w1 + p2*w2 + p3*w3 under the same contraction rule:
+ * t = p2*w2; t = fma(p1,w1,t); t = fma(p3,w3,t). */
+ORACLE_API void oracle_three_interpolate(int b, int c, int m, int n,
+                                         const float *points, const int *idx,
+                                         const float *weight, float *out) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *pp = points + (size_t)bi * m * c;
+    const int *pi = idx + (size_t)bi * n * 3;
+    const float *pw = weight + (size_t)bi * n * 3;
+    float *po = out + (size_t)bi * n * c;
+#pragma omp parallel for
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < n; ++j) {
+        const float w1 = pw[j * 3 + 0], w2 = pw[j * 3 + 1], w3 = pw[j * 3 + 2];
+        const int i1 = pi[j * 3 + 0], i2 = pi[j * 3 + 1], i3 = pi[j * 3 + 2];
+        float t = pp[(size_t)l * m + i2] * w2;
+        t = fmaf(pp[(size_t)l * m + i1], w1, t);
+        t = fmaf(pp[(size_t)l * m + i3], w3, t);
+        po[(size_t)l * n + j] = t;
+      }
+  }
+}
+
+/* K9: three_interpolate_grad -- interpolate_gpu.cu:116-143 */
+ORACLE_API void oracle_three_interpolate_grad(int b, int c, int n, int m,
+                                              const float *grad_out,
+                                              const int *idx,
+                                              const float *weight,
+                                              float *grad_points) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *go = grad_out + (size_t)bi * n * c;
+    const int *pi = idx + (size_t)bi * n * 3;
+    const float *pw = weight + (size_t)bi * n * 3;
+    float *gp = grad_points + (size_t)bi * m * c;
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < n; ++j) {
+        const float g = go[(size_t)l * n + j];
+        gp[(size_t)l * m + pi[j * 3 + 0]] += g * pw[j * 3 + 0];
+        gp[(size_t)l * m + pi[j * 3 + 1]] += g * pw[j * 3 + 1];
+        gp[(size_t)l * m + pi[j * 3 + 2]] += g * pw[j * 3 + 2];
+      }
+  }
+}
+
+/* ---- C1: occupancy decoder (DecoderCBatchNorm) ---------------------------
+ * models/iscnet/modules/occ_decoder.py:110-123 (forward),
+ * layers.py:98-107 (CResnetBlockConv1d.forward), layers.py:226-242
+ * (CBatchNorm1d.forward, BatchNorm1d(affine=False) in eval mode, eps 1e-5).
+ *
+ * Parameter blob layout (float32, H=hidden=256, C=c_dim, Z=z_dim), in the
+ * order of the reference state_dict:
+ *   fc_p.w[H*3] fc_p.b[H] fc_z.w[H*Z] fc_z.b[H]
+ *   5 x { bn_0{gw[H*C] gb[H] bw[H*C] bb[H] mean[H] var[H]}  fc_0{w[H*H] b[H]}
+ *         bn_1{...}                                          fc_1{w[H*H] b[H]} }
+ *   bn{gw gb bw bb mean var}  fc_out.w[H] fc_out.b[1]
+ * Inputs p (K,T,3), z (K,Z), c (K,C); output logits (K,T).
+ * Not pre-folded: gamma/beta/BN are evaluated the way the module does. */
+#define OR_EPS 1e-5f
+
+typedef struct {
+  const float *gw, *gb, *bw, *bb, *mean, *var;
+} or_cbn_t;
+
+static const float *take(const float **p, size_t n) {
+  const float *r = *p;
+  *p += n;
+  return r;
+}
+
+static void read_cbn(const float **p, int H, int C, or_cbn_t *o) {
+  o->gw = take(p, (size_t)H * C);
+  o->gb = take(p, H);
+  o->bw = take(p, (size_t)H * C);
+  o->bb = take(p, H);
+  o->mean = take(p, H);
+  o->var = take(p, H);
+}
+
+/* gamma[h] = gw[h,:]·c + gb[h]; beta likewise (Conv1d c_dim->f_dim, k=1) */
+static void cbn_affine(const or_cbn_t *q, const float *c, int H, int C,
+                       float *gamma, float *beta) {
+  for (int h = 0; h < H; ++h) {
+    float g = q->gb[h], be = q->bb[h];
+    for (int i = 0; i < C; ++i) {
+      g += q->gw[(size_t)h * C + i] * c[i];
+      be += q->bw[(size_t)h * C + i] * c[i];
+    }
+    gamma[h] = g;
+    beta[h] = be;
+  }
+}
+
+/* out = relu(gamma * (x-mean)/sqrt(var+eps) + beta) */
+static inline void cbn_relu(const or_cbn_t *q, const float *gamma,
+                            const float *beta, const float *x, float *out,
+                            int H) {
+  for (int h = 0; h < H; ++h) {
+    const float nrm = (x[h] - q->mean[h]) / sqrtf(q->var[h] + OR_EPS);
+    const float v = gamma[h] * nrm + beta[h];
+    out[h] = v > 0.f ? v : 0.f;
+  }
+}
+
+/* y[o] = b[o] + sum_k W[o,k] a[k], Wt is the transposed copy [k][o] so the
+ * inner loop vectorises (summation order: k ascending per output). */
+static inline void fc(const float *Wt, const float *bias, const float *a,
+                      float *y, int H) {
+  for (int o = 0; o < H; ++o) y[o] = bias[o];
+  for (int k = 0; k < H; ++k) {
+    const float ak = a[k];
+    const float *w = Wt + (size_t)k * H;
+    for (int o = 0; o < H; ++o) y[o] += w[o] * ak;
+  }
+}
+
+ORACLE_API void oracle_decoder_cbn(int K, int T, int H, int C, int Z,
+                                   const float *params, const float *p,
+                                   const float *z, const float *c,
+                                   float *logits) {
+  const float *q = params;
+  const float *fcp_w = take(&q, (size_t)H * 3), *fcp_b = take(&q, H);
+  const float *fcz_w = take(&q, (size_t)H * Z), *fcz_b = take(&q, H);
+  or_cbn_t bn[11];
+  const float *fw[10], *fb[10];
+  for (int i = 0; i < 5; ++i) {
+    read_cbn(&q, H, C, &bn[2 * i]);
+    fw[2 * i] = take(&q, (size_t)H * H);
+    fb[2 * i] = take(&q, H);
+    read_cbn(&q, H, C, &bn[2 * i + 1]);
+    fw[2 * i + 1] = take(&q, (size_t)H * H);
+    fb[2 * i + 1] = take(&q, H);
+  }
+  read_cbn(&q, H, C, &bn[10]);
+  const float *fo_w = take(&q, H), *fo_b = take(&q, 1);
+
+  /* transposed weight copies */
+  float *Wt = (float *)malloc(sizeof(float) * 10 * (size_t)H * H);
+  for (int l = 0; l < 10; ++l)
+    for (int o = 0; o < H; ++o)
+      for (int k = 0; k < H; ++k)
+        Wt[((size_t)l * H + k) * H + o] = fw[l][(size_t)o * H + k];
+
+  for (int pi = 0; pi < K; ++pi) {
+    float *gamma = (float *)malloc(sizeof(float) * 11 * H);
+    float *beta = (float *)malloc(sizeof(float) * 11 * H);
+    float *zb = (float *)malloc(sizeof(float) * H);
+    for (int l = 0; l < 11; ++l)
+      cbn_affine(&bn[l], c + (size_t)pi * C, H, C, gamma + l * H, beta + l * H);
+    for (int h = 0; h < H; ++h) { /* fc_z(z): occ_decoder.py:115 */
+      float v = fcz_b[h];
+      for (int i = 0; i < Z; ++i) v += fcz_w[(size_t)h * Z + i] * z[(size_t)pi * Z + i];
+      zb[h] = v;
+    }
+#pragma omp parallel
+    {
+      float *net = (float *)malloc(sizeof(float) * H);
+      float *a = (float *)malloc(sizeof(float) * H);
+      float *hid = (float *)malloc(sizeof(float) * H);
+      float *dx = (float *)malloc(sizeof(float) * H);
+#pragma omp for schedule(static)
+      for (int t = 0; t < T; ++t) {
+        const float *pt = p + ((size_t)pi * T + t) * 3;
+        for (int h = 0; h < H; ++h) /* fc_p + fc_z: occ_decoder.py:112-115 */
+          net[h] = (fcp_b[h] + fcp_w[h * 3 + 0] * pt[0] + fcp_w[h * 3 + 1] * pt[1] +
+                    fcp_w[h * 3 + 2] * pt[2]) + zb[h];
+        for (int i = 0; i < 5; ++i) { /* layers.py:98-107 */
+          cbn_relu(&bn[2 * i], gamma + 2 * i * H, beta + 2 * i * H, net, a, H);
+          fc(Wt + (size_t)(2 * i) * H * H, fb[2 * i], a, hid, H);
+          cbn_relu(&bn[2 * i + 1], gamma + (2 * i + 1) * H, beta + (2 * i + 1) * H, hid, a, H);
+          fc(Wt + (size_t)(2 * i + 1) * H * H, fb[2 * i + 1], a, dx, H);
+          for (int h = 0; h < H; ++h) net[h] = net[h] + dx[h];
+        }
+        cbn_relu(&bn[10], gamma + 10 * H, beta + 10 * H, net, a, H);
+        float o = fo_b[0];
+        for (int h = 0; h < H; ++h) o += fo_w[h] * a[h];
+        logits[(size_t)pi * T + t] = o; /* occ_decoder.py:120-121 */
+      }
+      free(net); free(a); free(hid); free(dx);
+    }
+    free(gamma); free(beta); free(zb);
+  }
+  free(Wt);
+}
+
+/* ---- make_3d_grid -- external/common.py:157-176 --------------------------
+ * torch.linspace(lo, hi, n) inclusive of both ends, x-major flattening.
+ * torch's float linspace: step = (hi-lo)/(n-1); for i < n/2: lo + i*step,
+ * else hi - (n-1-i)*step (symmetric evaluation, ATen RangeFactories). */
+ORACLE_API void oracle_make_3d_grid(float lo, float hi, int n, float scale,
+                                    float *out /* n^3 x 3 */) {
+  float *ax = (float *)malloc(sizeof(float) * n);
+  const float step = n > 1 ? (hi - lo) / (float)(n - 1) : 0.f;
+  const int half = n / 2;
+  for (int i = 0; i < n; ++i)
+    ax[i] = i < half ? lo + step * (float)i : hi - step * (float)(n - 1 - i);
+  size_t o = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      for (int k = 0; k < n; ++k) {
+        out[o++] = scale * ax[i];
+        out[o++] = scale * ax[j];
+        out[o++] = scale * ax[k];
+      }
+  free(ax);
+}
+
+/* ---- C3: MISE -- external/libmise/mise.pyx:33-369 ------------------------
+ * Same data structures (voxel vector with 2x2x2 child indices, grid-point
+ * vector in insertion order, coordinate -> index lookup); the std::map
+ * grid_point_hash (mise.pyx:36,356-360) is replaced by a dense int array
+ * over the (R+1)^3 lattice -- identical lookups, no ordering dependence. */
+typedef struct { int x, y, z; } or_vec3;
+typedef struct {
+  or_vec3 loc;
+  unsigned level;
+  int is_leaf;
+  long children[2][2][2];
+} or_voxel;
+typedef struct {
+  or_vec3 loc;
+  double value;
+  int known;
+} or_gpoint;
+
+typedef struct {
+  or_voxel *voxels;
+  size_t n_vox, cap_vox;
+  or_gpoint *gp;
+  size_t n_gp, cap_gp;
+  int *hash; /* (R+1)^3, -1 = absent */
+  int resolution_0, depth, voxel_size_0, resolution;
+  double threshold;
+} or_mise;
+
+static long vec_to_idx(or_vec3 c, long res) { /* mise.pyx:27-30 */
+  return res * res * c.x + res * c.y + c.z;
+}
+
+static void mise_add_gp(or_mise *m, or_vec3 loc) { /* mise.pyx:350-357 */
+  if (m->n_gp == m->cap_gp) {
+    m->cap_gp = m->cap_gp ? m->cap_gp * 2 : 1024;
+    m->gp = (or_gpoint *)realloc(m->gp, m->cap_gp * sizeof(or_gpoint));
+  }
+  m->hash[vec_to_idx(loc, m->resolution + 1)] = (int)m->n_gp;
+  or_gpoint g; g.loc = loc; g.value = 0.; g.known = 0;
+  m->gp[m->n_gp++] = g;
+}
+
+static int mise_gp_idx(const or_mise *m, or_vec3 loc) { /* mise.pyx:359-369 */
+  const int R1 = m->resolution + 1;
+  if (loc.x < 0 || loc.y < 0 || loc.z < 0 || loc.x >= R1 || loc.y >= R1 || loc.z >= R1)
+    return -1;
+  return m->hash[vec_to_idx(loc, R1)];
+}
+
+static void mise_push_voxel(or_mise *m, or_voxel v) {
+  if (m->n_vox == m->cap_vox) {
+    m->cap_vox = m->cap_vox ? m->cap_vox * 2 : 1024;
+    m->voxels = (or_voxel *)realloc(m->voxels, m->cap_vox * sizeof(or_voxel));
+  }
+  m->voxels[m->n_vox++] = v;
+}
+
+ORACLE_API void *oracle_mise_create(int resolution_0, int depth, double threshold) {
+  or_mise *m = (or_mise *)calloc(1, sizeof(or_mise)); /* mise.pyx:43-85 */
+  m->resolution_0 = resolution_0;
+  m->depth = depth;
+  m->threshold = threshold;
+  m->voxel_size_0 = 1 << depth;
+  m->resolution = resolution_0 * m->voxel_size_0;
+  const size_t R1 = (size_t)m->resolution + 1;
+  m->hash = (int *)malloc(sizeof(int) * R1 * R1 * R1);
+  for (size_t i = 0; i < R1 * R1 * R1; ++i) m->hash[i] = -1;
+  for (int i = 0; i < resolution_0; ++i)
+    for (int j = 0; j < resolution_0; ++j)
+      for (int k = 0; k < resolution_0; ++k) {
+        or_voxel v; memset(&v, 0, sizeof(v));
+        v.loc.x = i * m->voxel_size_0; v.loc.y = j * m->voxel_size_0; v.loc.z = k * m->voxel_size_0;
+        v.level = 0; v.is_leaf = 1;
+        mise_push_voxel(m, v);
+      }
+  for (int i = 0; i <= resolution_0; ++i)
+    for (int j = 0; j <= resolution_0; ++j)
+      for (int k = 0; k <= resolution_0; ++k) {
+        or_vec3 loc = {i * m->voxel_size_0, j * m->voxel_size_0, k * m->voxel_size_0};
+        mise_add_gp(m, loc);
+      }
+  return m;
+}
+
+ORACLE_API void oracle_mise_destroy(void *h) {
+  or_mise *m = (or_mise *)h;
+  free(m->voxels); free(m->gp); free(m->hash); free(m);
+}
+
+ORACLE_API int oracle_mise_resolution(void *h) { return ((or_mise *)h)->resolution; }
+
+/* mise.pyx:300-347 get_voxel_idx */
+static long mise_voxel_idx(const or_mise *m, or_vec3 loc) {
+  const long res = m->resolution, depth = m->depth;
+  if (!(0 <= loc.x && loc.x < res && 0 <= loc.y && loc.y < res && 0 <= loc.z && loc.z < res))
+    return -1;
+  or_vec3 loc0 = {loc.x >> depth, loc.y >> depth, loc.z >> depth};
+  long idx = vec_to_idx(loc0, m->resolution_0);
+  const or_voxel *v = &m->voxels[idx];
+  or_vec3 rel = {loc.x - (loc0.x << depth), loc.y - (loc0.y << depth), loc.z - (loc0.z << depth)};
+  long vs = m->voxel_size_0;
+  while (!v->is_leaf) {
+    vs >>= 1;
+    const int ox = rel.x >= vs, oy = rel.y >= vs, oz = rel.z >= vs;
+    idx = v->children[ox][oy][oz];
+    v = &m->voxels[idx];
+    rel.x -= ox * vs; rel.y -= oy * vs; rel.z -= oz * vs;
+  }
+  return idx;
+}
+
+/* mise.pyx:253-283 subdivide_voxel */
+static void mise_subdivide_voxel(or_mise *m, long idx) {
+  const or_vec3 loc0 = m->voxels[idx].loc;
+  const int new_level = (int)m->voxels[idx].level + 1;
+  const int new_size = 1 << (m->depth - new_level);
+  m->voxels[idx].is_leaf = 0;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < 2; ++k) {
+        or_voxel v; memset(&v, 0, sizeof(v));
+        v.loc.x = loc0.x + i * new_size; v.loc.y = loc0.y + j * new_size; v.loc.z = loc0.z + k * new_size;
+        v.level = (unsigned)new_level; v.is_leaf = 1;
+        const long child = (long)m->n_vox;
+        mise_push_voxel(m, v); /* may realloc: re-index parent after */
+        m->voxels[idx].children[i][j][k] = child;
+      }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) {
+        or_vec3 loc = {loc0.x + i * new_size, loc0.y + j * new_size, loc0.z + k * new_size};
+        if (mise_gp_idx(m, loc) == -1) mise_add_gp(m, loc);
+      }
+}
+
+/* mise.pyx:196-251 subdivide_voxels */
+static void mise_subdivide_voxels(or_mise *m) {
+  const size_t nv = m->n_vox;
+  char *pos = (char *)calloc(nv, 1), *neg = (char *)calloc(nv, 1);
+  for (size_t g = 0; g < m->n_gp; ++g) {
+    const or_gpoint *gp = &m->gp[g];
+    if (!gp->known) continue;
+    for (int i = -1; i < 1; ++i)
+      for (int j = -1; j < 1; ++j)
+        for (int k = -1; k < 1; ++k) {
+          or_vec3 adj = {gp->loc.x + i, gp->loc.y + j, gp->loc.z + k};
+          const long idx = mise_voxel_idx(m, adj);
+          if (idx == -1) continue;
+          if (gp->value >= m->threshold) pos[idx] = 1; /* :225 non-strict */
+          if (gp->value <= m->threshold) neg[idx] = 1; /* :227 non-strict */
+        }
+  }
+  for (size_t idx = 0; idx < nv; ++idx) { /* iterate the pre-split voxel set */
+    if (!m->voxels[idx].is_leaf || (int)m->voxels[idx].level == m->depth) continue;
+    if (pos[idx] && neg[idx]) mise_subdivide_voxel(m, (long)idx);
+  }
+  free(pos); free(neg);
+}
+
+/* mise.pyx:106-131 query: unknown points in insertion order; returns count,
+ * writes up to cap points (int64 x 3). Call with out=NULL to get the count. */
+ORACLE_API long oracle_mise_query(void *h, int64_t *out, long cap) {
+  or_mise *m = (or_mise *)h;
+  long n = 0;
+  for (size_t g = 0; g < m->n_gp; ++g)
+    if (!m->gp[g].known) {
+      if (out && n < cap) {
+        out[n * 3 + 0] = m->gp[g].loc.x; out[n * 3 + 1] = m->gp[g].loc.y; out[n * 3 + 2] = m->gp[g].loc.z;
+      }
+      ++n;
+    }
+  return n;
+}
+
+/* mise.pyx:87-104 update; returns -1 if a point is not in the grid */
+ORACLE_API int oracle_mise_update(void *h, const int64_t *points, const double *values, long n) {
+  or_mise *m = (or_mise *)h;
+  for (long i = 0; i < n; ++i) {
+    or_vec3 loc = {(int)points[i * 3 + 0], (int)points[i * 3 + 1], (int)points[i * 3 + 2]};
+    const int idx = mise_gp_idx(m, loc);
+    if (idx == -1) return -1;
+    m->gp[idx].value = values[i];
+    m->gp[idx].known = 1;
+  }
+  mise_subdivide_voxels(m);
+  return 0;
+}
+
+/* mise.pyx:133-163 to_dense: scatter then forward-fill NaNs along x, y, z */
+ORACLE_API void oracle_mise_to_dense(void *h, double *out) {
+  or_mise *m = (or_mise *)h;
+  const long R1 = m->resolution + 1;
+#define AT(i, j, k) out[((i) * R1 + (j)) * R1 + (k)]
+  for (long i = 0; i < R1 * R1 * R1; ++i) out[i] = NAN;
+  for (size_t g = 0; g < m->n_gp; ++g) /* note: unknown points scatter 0.0 */
+    AT(m->gp[g].loc.x, m->gp[g].loc.y, m->gp[g].loc.z) = m->gp[g].value;
+  for (long i = 1; i < R1; ++i)
+    for (long j = 0; j < R1; ++j)
+      for (long k = 0; k < R1; ++k)
+        if (isnan(AT(i, j, k))) AT(i, j, k) = AT(i - 1, j, k);
+  for (long i = 0; i < R1; ++i)
+    for (long j = 1; j < R1; ++j)
+      for (long k = 0; k < R1; ++k)
+        if (isnan(AT(i, j, k))) AT(i, j, k) = AT(i, j - 1, k);
+  for (long i = 0; i < R1; ++i)
+    for (long j = 0; j < R1; ++j)
+      for (long k = 1; k < R1; ++k)
+        if (isnan(AT(i, j, k))) AT(i, j, k) = AT(i, j, k - 1);
+#undef AT
+}

@@ -1,0 +1,94 @@
+"""ctypes binding of librfd_hip.so -- the C-ABI boundary (include/*.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to
+load, importing an op raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from this package.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librfd_hip.so")
+
+_f = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+_i = C.c_int
+_fl = C.c_float
+
+# name -> argtypes, exactly the prototypes of include/rfd_pointnet2.h / rfd_occ.h
+SIGNATURES = {
+    "furthest_point_sampling_kernel_wrapper": [_i, _i, _i, _f, _f, _f, _f],
+    "gather_points_kernel_wrapper": [_i, _i, _i, _i, _f, _f, _f, _f],
+    "gather_points_grad_kernel_wrapper": [_i, _i, _i, _i, _f, _f, _f, _f],
+    "query_ball_point_kernel_wrapper": [_i, _i, _i, _fl, _i, _f, _f, _f, _f],
+    "group_points_kernel_wrapper": [_i, _i, _i, _i, _i, _f, _f, _f, _f],
+    "group_points_grad_kernel_wrapper": [_i, _i, _i, _i, _i, _f, _f, _f, _f],
+    "three_nn_kernel_wrapper": [_i, _i, _i, _f, _f, _f, _f, _f],
+    "three_interpolate_kernel_wrapper": [_i, _i, _i, _i, _f, _f, _f, _f, _f],
+    "three_interpolate_grad_kernel_wrapper": [_i, _i, _i, _i, _f, _f, _f, _f, _f],
+    "rfd_group_concat": [_i, _i, _i, _i, _i, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f],
+    "rfd_furthest_point_sampling_gather": [_i, _i, _i, _f, _f, _f, _f, _f],
+    "rfd_occ_pack_weights": [_f, _f, C.POINTER(C.c_int), _i, _f, _f],
+    "rfd_occ_decode": [_i, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],
+}
+_RESTYPES = {
+    "rfd_last_error_string": C.c_char_p,
+    "rfd_build_arch": C.c_char_p,
+    "rfd_device_status": C.c_int,
+    "rfd_occ_packed_bytes": C.c_size_t,
+}
+
+_lib = None
+
+
+class RfdHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librfd_hip.so (once).  Raises if it is absent -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RfdHipError(
+                "librfd_hip.so not built (%s). Run `python -m rfdnet_amd.build` "
+                "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        for name, rt in _RESTYPES.items():
+            fn = getattr(l, name)
+            fn.restype = rt
+            fn.argtypes = []
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(list(SIGNATURES) + list(_RESTYPES))
+
+
+def check(rc, what):
+    """hipError_t -> Python exception (the reference exit(-1)s instead,
+    cuda_utils.h:30-39)."""
+    if rc != 0:
+        msg = lib().rfd_last_error_string()
+        raise RfdHipError("%s failed (hipError %d): %s" % (what, rc, (msg or b"").decode()))
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_status():
+    """Synchronises; raises if a persistent kernel flagged a problem."""
+    st = lib().rfd_device_status()
+    if st < 0:
+        raise RfdHipError("rfd_device_status failed")
+    if st & 1:
+        raise RfdHipError("FPS inter-workgroup exchange timed out")
+    if st & 2:
+        raise RfdHipError("occupancy decoder: activation exceeded the f16 range")
+    return st

@@ -1,0 +1,50 @@
+"""Build librfd_hip.so (the HIP/C-ABI library) for gfx950 with hipcc.
+
+In-tree build: the .so lands in rfdnet_amd/lib/ so it travels with the repo
+snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+hipcc cross-compiles gfx950 without a GPU present.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "librfd_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+# -ffp-contract=off: the fma placement in the point ops is part of the
+# bit-exactness contract (csrc/common.h sumsq3), so nothing may be contracted
+# implicitly.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-fPIC", "-shared", "-fvisibility=hidden", "-I" + INCLUDE]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,62 @@
+// common.h -- shared device/host helpers of librfd_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define RFD_API extern "C" __attribute__((visibility("default")))
+
+// ---- error plumbing ---------------------------------------------------------
+void rfd_set_error(const char *where, hipError_t e);
+
+#define RFD_CHECK(expr)                        \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) {                    \
+      rfd_set_error(#expr, _e);                \
+      return (int)_e;                          \
+    }                                          \
+  } while (0)
+
+#define RFD_CHECK_LAUNCH()                     \
+  do {                                         \
+    hipError_t _e = hipGetLastError();         \
+    if (_e != hipSuccess) {                    \
+      rfd_set_error(__func__, _e);             \
+      return (int)_e;                          \
+    }                                          \
+  } while (0)
+
+// Per-device scratch shared by the persistent kernels (FPS granule exchange,
+// status word).  Allocated once per device, never freed.
+struct RfdWorkspace {
+  unsigned long long *fps_slots;  // FPS_RING regions of FPS_REGION_GRANULES
+  unsigned *status;               // device status word (0 = OK)
+  unsigned ring_pos;
+};
+constexpr int FPS_RING = 16;
+constexpr int FPS_MAX_WG = 256;                         // co-resident WGs/launch
+constexpr int FPS_REGION_GRANULES = FPS_MAX_WG * 2 * 5; // [wg][parity][field]
+int rfd_get_workspace(RfdWorkspace **ws);
+
+// ---- arithmetic contract ------------------------------------------------------
+// a*a + b*b + c*c as nvcc -fmad=true contracts it (see oracle/rfd_oracle.c
+// header): t = b*b; t = fma(a,a,t); t = fma(c,c,t).  The library is compiled
+// with -ffp-contract=off so this order is exact.
+__device__ __forceinline__ float sumsq3(float a, float b, float c) {
+  float t = b * b;
+  t = __builtin_fmaf(a, a, t);
+  t = __builtin_fmaf(c, c, t);
+  return t;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// cuda_utils.h:13-19 -- needed host-side only to reproduce the FPS tie order.
+static inline int ref_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int v = 1 << pow_2;
+  if (v > 512) v = 512;
+  if (v < 1) v = 1;
+  return v;
+}

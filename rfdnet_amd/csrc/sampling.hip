@@ -1,0 +1,350 @@
+// sampling.hip -- furthest point sampling + gather_points for gfx950.
+//
+// Replaces external/pointnet2_ops_lib/pointnet2_ops/_ext-src/src/sampling_gpu.cu
+// (K1 furthest_point_sampling_kernel :69-173, K2 gather_points_kernel :8-20,
+// K3 gather_points_grad_kernel :34-47).  Not a translation: the reference runs
+// ONE 512-thread block per scene that re-streams all n points from L2/HBM in
+// each of the m-1 serial rounds.  Here a scene is spread over G workgroups
+// whose points (xyz, running min-distance, tie rank) live in REGISTERS for the
+// whole kernel; a round is
+//   local update + per-lane argmax  ->  wave argmax (cross-lane shuffles)
+//   ->  workgroup argmax (LDS, one barrier)
+//   ->  (G > 1) all-to-all exchange of the G candidates through 8-byte
+//       {round-tag, value} granules in global memory (relaxed agent-scope
+//       atomics; the data is its own flag) -> every wave picks the winner.
+// HBM traffic is the algorithmic minimum: 12 B/point in, 4 B/point (temp) +
+// 4 B/sample out.
+//
+// Bit-exactness with the CUDA kernel, including ties: the CUDA result is the
+// maximum of d2 where equal values are ordered by (bit-reversed thread id
+// k mod BS, then k / BS) -- thread-local strict '>' keeps the lowest k, the
+// shared-memory tree keeps the left operand on ties (sampling_gpu.cu:59-65).
+// We reduce on the 64-bit key (d2 bits << 32 | ~rank(k)) with
+// rank(k) = bitrev(k mod BS) * ceil(n/BS) + k / BS, BS = opt_n_threads(n)
+// (cuda_utils.h:13-19), which is a total order, so any reduction tree gives
+// the CUDA answer.  d2 >= 0, so its bit pattern is monotone as unsigned.
+#include "common.h"
+
+namespace {
+
+constexpr int FPS_THREADS = 256;
+constexpr int FPS_WAVES = FPS_THREADS / 64;
+constexpr unsigned FPS_SPIN_LIMIT = 1u << 22;
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = __shfl_xor(lo, mask);
+  hi = __shfl_xor(hi, mask);
+  return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const u64 o = shfl_xor_u64(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+struct Cand {
+  u64 key;  // (d2 bits << 32) | ~rank, 0 = no valid point
+  int k;
+  float x, y, z;
+};
+
+// Broadcast the candidate of the (unique) lane whose key equals the wave max.
+__device__ __forceinline__ Cand wave_select(const Cand &c) {
+  Cand r;
+  r.key = wave_max_u64(c.key);
+  const u64 m = __ballot(c.key == r.key);
+  const int src = __ffsll((long long)m) - 1;
+  r.k = __shfl(c.k, src);
+  r.x = __shfl(c.x, src);
+  r.y = __shfl(c.y, src);
+  r.z = __shfl(c.z, src);
+  return r;
+}
+
+__device__ __forceinline__ unsigned fps_rank(int k, int bs_log2, int cpb) {
+  const unsigned tid = (unsigned)k & ((1u << bs_log2) - 1u);
+  const unsigned rev = bs_log2 ? (__brev(tid) >> (32 - bs_log2)) : 0u;
+  return rev * (unsigned)cpb + ((unsigned)k >> bs_log2);
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
+    int n, int m, int G, int bs_log2, int cpb, const float *__restrict__ dataset,
+    float *__restrict__ temp, int *__restrict__ idxs,
+    float *__restrict__ new_xyz, u64 *slots, unsigned *status) {
+  const int batch = blockIdx.x / G;
+  const int g = blockIdx.x - batch * G;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  dataset += (size_t)batch * n * 3;
+  temp += (size_t)batch * n;
+  idxs += (size_t)batch * m;
+  if (new_xyz) new_xyz += (size_t)batch * m * 3;
+  slots += (size_t)batch * G * 10;  // [g][parity][5]
+
+  __shared__ u64 s_key[2][FPS_WAVES];
+  __shared__ int s_k[2][FPS_WAVES];
+  __shared__ float s_xyz[2][FPS_WAVES][3];
+
+  // ---- load this thread's points once; they stay in registers ----
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  unsigned nrank[PPT];  // ~rank, 0 = point absent or skipped
+  const int base = g * (PPT * FPS_THREADS) + t;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = base + i * FPS_THREADS;
+    const bool in = k < n;
+    px[i] = in ? dataset[(size_t)k * 3 + 0] : 0.f;
+    py[i] = in ? dataset[(size_t)k * 3 + 1] : 0.f;
+    pz[i] = in ? dataset[(size_t)k * 3 + 2] : 0.f;
+    td[i] = 1e10f;  // sampling.cpp:74-76
+    const float mag = sumsq3(px[i], py[i], pz[i]);       // sampling_gpu.cu:100
+    const bool skip = !in || ((double)mag <= 1e-3);      // :101 (double literal)
+    nrank[i] = skip ? 0u : ~fps_rank(k, bs_log2, cpb);
+  }
+  const float p0x = dataset[0], p0y = dataset[1], p0z = dataset[2];
+
+  float cx = p0x, cy = p0y, cz = p0z;  // old = 0 (:86)
+  if (g == 0 && t == 0) {
+    idxs[0] = 0;
+    if (new_xyz) { new_xyz[0] = p0x; new_xyz[1] = p0y; new_xyz[2] = p0z; }
+  }
+
+  for (int j = 1; j < m; ++j) {
+    const int par = j & 1;
+    // ---- local update + argmax over this thread's points ----
+    Cand c;
+    c.key = 0; c.k = 0; c.x = p0x; c.y = p0y; c.z = p0z;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sumsq3(px[i] - cx, py[i] - cy, pz[i] - cz);  // :103-104
+      const float d2 = fminf(d, td[i]);                             // :106
+      const bool ok = nrank[i] != 0u;
+      td[i] = ok ? d2 : td[i];
+      const u64 key = ok ? (((u64)__float_as_uint(d2) << 32) | nrank[i]) : 0ull;
+      const bool better = key > c.key;
+      c.key = better ? key : c.key;
+      c.k = better ? base + i * FPS_THREADS : c.k;
+      c.x = better ? px[i] : c.x;
+      c.y = better ? py[i] : c.y;
+      c.z = better ? pz[i] : c.z;
+    }
+    // ---- wave argmax, then workgroup argmax through LDS ----
+    Cand w = wave_select(c);
+    if (lane == 0) {
+      s_key[par][wave] = w.key;
+      s_k[par][wave] = w.k;
+      s_xyz[par][wave][0] = w.x;
+      s_xyz[par][wave][1] = w.y;
+      s_xyz[par][wave][2] = w.z;
+    }
+    __syncthreads();
+    Cand b;
+    b.key = s_key[par][0]; b.k = s_k[par][0];
+    b.x = s_xyz[par][0][0]; b.y = s_xyz[par][0][1]; b.z = s_xyz[par][0][2];
+#pragma unroll
+    for (int q = 1; q < FPS_WAVES; ++q) {
+      const u64 kq = s_key[par][q];
+      const bool better = kq > b.key;
+      b.key = better ? kq : b.key;
+      b.k = better ? s_k[par][q] : b.k;
+      b.x = better ? s_xyz[par][q][0] : b.x;
+      b.y = better ? s_xyz[par][q][1] : b.y;
+      b.z = better ? s_xyz[par][q][2] : b.z;
+    }
+    if (G > 1) {
+      // ---- publish this workgroup's candidate: 5 tagged granules ----
+      u64 *mine = slots + ((size_t)g * 2 + par) * 5;
+      if (t < 5) {
+        unsigned payload = (unsigned)(b.key >> 32);
+        payload = t == 1 ? (b.key ? (unsigned)b.k : 0xffffffffu) : payload;
+        payload = t == 2 ? __float_as_uint(b.x) : payload;
+        payload = t == 3 ? __float_as_uint(b.y) : payload;
+        payload = t == 4 ? __float_as_uint(b.z) : payload;
+        __hip_atomic_store(mine + t, ((u64)(unsigned)j << 32) | payload,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // ---- every wave gathers all G candidates (lane = workgroup) ----
+      const u64 *theirs = slots + ((size_t)lane * 2 + par) * 5;
+      unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+        if (lane < G) {
+          const u64 g0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const u64 g1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const u64 g2 = __hip_atomic_load(theirs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const u64 g3 = __hip_atomic_load(theirs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const u64 g4 = __hip_atomic_load(theirs + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned tag = (unsigned)j;
+          ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag &&
+               (unsigned)(g2 >> 32) == tag && (unsigned)(g3 >> 32) == tag &&
+               (unsigned)(g4 >> 32) == tag;
+          f0 = (unsigned)g0; f1 = (unsigned)g1; f2 = (unsigned)g2;
+          f3 = (unsigned)g3; f4 = (unsigned)g4;
+        }
+        if (__all(ok)) break;
+        if (++spins > FPS_SPIN_LIMIT) {  // bounded spin: flag and bail out
+          if (lane == 0) atomicOr(status, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      // a workgroup without a valid point publishes k = -1; rank is recomputed
+      // from k so ties between workgroups order exactly as in the CUDA tree
+      Cand o;
+      const bool valid = lane < G && (int)f1 >= 0;
+      o.key = valid ? (((u64)f0 << 32) | (u64)(~fps_rank((int)f1, bs_log2, cpb))) : 0ull;
+      o.k = (int)f1;
+      o.x = __uint_as_float(f2);
+      o.y = __uint_as_float(f3);
+      o.z = __uint_as_float(f4);
+      b = wave_select(o);
+    }
+    if (b.key == 0ull) { b.k = 0; b.x = p0x; b.y = p0y; b.z = p0z; }  // all skipped
+    cx = b.x; cy = b.y; cz = b.z;  // old = dists_i[0] (:170)
+    if (g == 0 && t == 0) {
+      idxs[j] = b.k;
+      if (new_xyz) { new_xyz[j * 3 + 0] = b.x; new_xyz[j * 3 + 1] = b.y; new_xyz[j * 3 + 2] = b.z; }
+    }
+  }
+  // the CUDA kernel leaves the final min-distances in temp
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = base + i * FPS_THREADS;
+    if (k < n) temp[k] = td[i];
+  }
+}
+
+__global__ void gather_points_kernel(int c, int n, int m,
+                                     const float *__restrict__ points,
+                                     const int *__restrict__ idx,
+                                     float *__restrict__ out) {
+  // grid (ceil(m/256), c, b): out[b,l,j] = points[b,l,idx[b,j]]
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = blockIdx.y, bi = blockIdx.z;
+  if (j >= m) return;
+  const int a = idx[(size_t)bi * m + j];
+  out[((size_t)bi * c + l) * m + j] = points[((size_t)bi * c + l) * n + a];
+}
+
+__global__ void gather_points_grad_kernel(int c, int n, int m,
+                                          const float *__restrict__ grad_out,
+                                          const int *__restrict__ idx,
+                                          float *__restrict__ grad_points) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = blockIdx.y, bi = blockIdx.z;
+  if (j >= m) return;
+  const int a = idx[(size_t)bi * m + j];
+  atomicAdd(grad_points + ((size_t)bi * c + l) * n + a,
+            grad_out[((size_t)bi * c + l) * m + j]);
+}
+
+template <int PPT>
+int launch_fps(int nb, int n, int m, int G, int bs_log2, int cpb,
+               const float *dataset, float *temp, int *idxs, float *new_xyz,
+               u64 *slots, unsigned *status, hipStream_t s) {
+  hipLaunchKernelGGL(fps_kernel<PPT>, dim3(nb * G), dim3(FPS_THREADS), 0, s, n,
+                     m, G, bs_log2, cpb, dataset, temp, idxs, new_xyz, slots,
+                     status);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+             float *new_xyz, void *stream) {
+  if (m <= 0 || b <= 0) return 0;  // sampling_gpu.cu:73
+  if (n <= 0) { rfd_set_error("furthest_point_sampling: n <= 0", hipErrorInvalidValue); return (int)hipErrorInvalidValue; }
+  hipStream_t s = (hipStream_t)stream;
+  RfdWorkspace *ws;
+  int rc = rfd_get_workspace(&ws);
+  if (rc) return rc;
+  // geometry: G workgroups x 256 threads x PPT points cover n
+  const int per_thread = ceil_div(n, FPS_THREADS);
+  int ppt, G;
+  if (per_thread <= 16) {  // one workgroup holds the scene
+    G = 1;
+    ppt = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : per_thread <= 8 ? 8 : 16;
+  } else {
+    // aim at ~10 points/thread; more when the scene would need > 64 workgroups
+    ppt = 10;
+    G = ceil_div(n, FPS_THREADS * ppt);
+    if (G > 64) { ppt = 16; G = ceil_div(n, FPS_THREADS * ppt); }
+    if (G > 64) { ppt = 32; G = ceil_div(n, FPS_THREADS * ppt); }
+    if (G > 64) { ppt = 64; G = ceil_div(n, FPS_THREADS * ppt); }
+    if (G > 64) { rfd_set_error("furthest_point_sampling: n > 1048576 unsupported", hipErrorInvalidValue); return (int)hipErrorInvalidValue; }
+  }
+  const int bs = ref_opt_n_threads(n);
+  int bs_log2 = 0;
+  while ((1 << bs_log2) < bs) ++bs_log2;
+  const int cpb = ceil_div(n, bs);
+  const int batches_per_launch = G > 1 ? (FPS_MAX_WG / G) : b;
+  for (int b0 = 0; b0 < b; b0 += batches_per_launch) {
+    const int nb = (b - b0) < batches_per_launch ? (b - b0) : batches_per_launch;
+    u64 *slots = nullptr;
+    if (G > 1) {
+      slots = ws->fps_slots + (size_t)(ws->ring_pos++ % FPS_RING) * FPS_REGION_GRANULES;
+      RFD_CHECK(hipMemsetAsync(slots, 0, sizeof(u64) * (size_t)nb * G * 10, s));
+    }
+    const float *ds = dataset + (size_t)b0 * n * 3;
+    float *tp = temp + (size_t)b0 * n;
+    int *ix = idxs + (size_t)b0 * m;
+    float *nx = new_xyz ? new_xyz + (size_t)b0 * m * 3 : nullptr;
+    switch (ppt) {
+#define FPS_CASE(P) case P: rc = launch_fps<P>(nb, n, m, G, bs_log2, cpb, ds, tp, ix, nx, slots, ws->status, s); break;
+      FPS_CASE(1) FPS_CASE(2) FPS_CASE(4) FPS_CASE(8) FPS_CASE(10) FPS_CASE(16) FPS_CASE(32) FPS_CASE(64)
+#undef FPS_CASE
+      default: rc = (int)hipErrorInvalidValue;
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
+RFD_API int furthest_point_sampling_kernel_wrapper(int b, int n, int m,
+                                                   const float *dataset,
+                                                   float *temp, int *idxs,
+                                                   void *stream) {
+  return fps_impl(b, n, m, dataset, temp, idxs, nullptr, stream);
+}
+
+RFD_API int rfd_furthest_point_sampling_gather(int b, int n, int m,
+                                               const float *dataset,
+                                               float *temp, int *idxs,
+                                               float *new_xyz, void *stream) {
+  return fps_impl(b, n, m, dataset, temp, idxs, new_xyz, stream);
+}
+
+RFD_API int gather_points_kernel_wrapper(int b, int c, int n, int npoints,
+                                         const float *points, const int *idx,
+                                         float *out, void *stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return 0;
+  hipLaunchKernelGGL(gather_points_kernel, dim3(ceil_div(npoints, 256), c, b),
+                     dim3(256), 0, (hipStream_t)stream, c, n, npoints, points,
+                     idx, out);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API int gather_points_grad_kernel_wrapper(int b, int c, int n, int npoints,
+                                              const float *grad_out,
+                                              const int *idx,
+                                              float *grad_points,
+                                              void *stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return 0;
+  hipLaunchKernelGGL(gather_points_grad_kernel,
+                     dim3(ceil_div(npoints, 256), c, b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, npoints, grad_out, idx,
+                     grad_points);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}

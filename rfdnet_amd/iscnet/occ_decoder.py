@@ -1,0 +1,165 @@
+"""DecoderCBatchNorm with the reference's constructor, forward signature and
+state_dict keys (models/iscnet/modules/occ_decoder.py:72-123, layers.py:51-107,
+193-242), evaluated by ONE fused HIP kernel (csrc/occ_decoder.hip).
+
+state_dict keys (verified against the reference class by
+tests/golden/make_fixtures.py):  fc_p.{weight(256,3,1),bias}, fc_z.{weight
+(256,Z),bias}, blocks.{0-4}.{bn_0,bn_1}.{conv_gamma,conv_beta}.{weight
+(256,C,1),bias}, blocks.{i}.{bn_0,bn_1}.bn.{running_mean,running_var,
+num_batches_tracked}, blocks.{i}.{fc_0,fc_1}.{weight(256,256,1),bias}, bn.*,
+fc_out.{weight(1,256,1),bias}.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, occ_fold
+
+MODE_F16X3 = 3   # parity mode (fp32-class logits)
+MODE_F16X1 = 1   # throughput mode
+TILE = 128
+
+
+class CBatchNorm1d(nn.Module):
+    """Parameter container of layers.py:193-242 (conv_gamma, conv_beta, bn)."""
+
+    def __init__(self, c_dim, f_dim, norm_method='batch_norm'):
+        super().__init__()
+        if norm_method != 'batch_norm':
+            raise NotImplementedError("only batch_norm is on the inference path")
+        self.c_dim = c_dim
+        self.f_dim = f_dim
+        self.norm_method = norm_method
+        self.conv_gamma = nn.Conv1d(c_dim, f_dim, 1)
+        self.conv_beta = nn.Conv1d(c_dim, f_dim, 1)
+        self.bn = nn.BatchNorm1d(f_dim, affine=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):            # layers.py:219-224
+        nn.init.zeros_(self.conv_gamma.weight)
+        nn.init.zeros_(self.conv_beta.weight)
+        nn.init.ones_(self.conv_gamma.bias)
+        nn.init.zeros_(self.conv_beta.bias)
+
+
+class CResnetBlockConv1d(nn.Module):
+    """Parameter container of layers.py:51-107 (size_in == size_h == size_out)."""
+
+    def __init__(self, c_dim, size_in, size_h=None, size_out=None,
+                 norm_method='batch_norm', legacy=False):
+        super().__init__()
+        if legacy:
+            raise NotImplementedError("legacy CBN is not on the inference path")
+        size_h = size_in if size_h is None else size_h
+        size_out = size_in if size_out is None else size_out
+        if not (size_in == size_h == size_out):
+            raise NotImplementedError("shortcut blocks are not used by DecoderCBatchNorm")
+        self.size_in, self.size_h, self.size_out = size_in, size_h, size_out
+        self.bn_0 = CBatchNorm1d(c_dim, size_in, norm_method=norm_method)
+        self.bn_1 = CBatchNorm1d(c_dim, size_h, norm_method=norm_method)
+        self.fc_0 = nn.Conv1d(size_in, size_h, 1)
+        self.fc_1 = nn.Conv1d(size_h, size_out, 1)
+        self.shortcut = None
+        nn.init.zeros_(self.fc_1.weight)   # layers.py:96
+
+
+class DecoderCBatchNorm(nn.Module):
+    def __init__(self, dim=3, z_dim=128, c_dim=128, hidden_size=256, n_blocks=5,
+                 leaky=False, legacy=False):
+        super().__init__()
+        if dim != 3 or hidden_size != 256 or n_blocks != 5 or leaky or legacy:
+            raise NotImplementedError(
+                "the fused HIP decoder is built for dim=3, hidden_size=256, "
+                "n_blocks=5, ReLU (the configuration RfD-Net instantiates, "
+                "occupancy_net.py:45)")
+        self.z_dim = z_dim
+        if not z_dim == 0:
+            self.fc_z = nn.Linear(z_dim, hidden_size)
+        self.fc_p = nn.Conv1d(dim, hidden_size, 1)
+        self.blocks = nn.ModuleList([CResnetBlockConv1d(c_dim, hidden_size)
+                                     for _ in range(n_blocks)])
+        self.bn = CBatchNorm1d(c_dim, hidden_size)
+        self.fc_out = nn.Conv1d(hidden_size, 1, 1)
+        self.mode = MODE_F16X3
+        self._packed = None
+        self._packed_key = None
+
+    # ---- weight stream (re-packed only when the parameters change) -----------
+    def _weights_key(self):
+        ps = [self.blocks[i].fc_0.weight for i in range(5)] + \
+             [self.blocks[i].fc_1.weight for i in range(5)]
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+
+    def packed_weights(self):
+        key = self._weights_key()
+        if self._packed is None or key != self._packed_key:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            fc0, fc1 = occ_fold.stacked_fc_weights(sd)
+            if not fc0.is_cuda:
+                raise RuntimeError("CPU not supported")
+            kw0 = [occ_fold.choose_kw([fc0[i]]) for i in range(5)]
+            kw1 = occ_fold.choose_kw([fc1])
+            packed = torch.empty(_lib.lib().rfd_occ_packed_bytes(), dtype=torch.uint8,
+                                 device=fc0.device)
+            arr = (C.c_int * 5)(*kw0)
+            with torch.cuda.device(fc0.device):
+                rc = _lib.lib().rfd_occ_pack_weights(fc0.data_ptr(), fc1.data_ptr(), arr, kw1,
+                                                     packed.data_ptr(), _lib.current_stream())
+            _lib.check(rc, "rfd_occ_pack_weights")
+            self._packed = (packed, kw0, kw1)
+            self._packed_key = key
+        return self._packed
+
+    def _fc_out_bias(self):
+        b = self.fc_out.bias
+        key = (b.data_ptr(), b._version)
+        if getattr(self, "_bo_cache", (None, None))[0] != key:
+            self._bo_cache = (key, float(b.detach().item()))   # one sync per weight load
+        return self._bo_cache[1]
+
+    def fold(self, z, c):
+        """Per-proposal table (K,23,256) + scaled fc_p weight for codes z, c."""
+        _, kw0, kw1 = self.packed_weights()
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        if self.z_dim == 0:
+            sd["fc_z.weight"] = torch.zeros(256, 0, device=c.device)
+            sd["fc_z.bias"] = torch.zeros(256, device=c.device)
+        return occ_fold.fold_table(sd, z, c, kw0, kw1)
+
+    def decode_tiles(self, pts, tile_prop, table, fc_p_w, mode=None):
+        """pts (n_tiles*128,3) f32, tile_prop (n_tiles,) i32 -> logits (n_tiles*128,)."""
+        packed, _, _ = self.packed_weights()
+        n_tiles = tile_prop.shape[0]
+        assert pts.is_contiguous() and pts.shape[0] == n_tiles * TILE and pts.dtype == torch.float32
+        assert tile_prop.dtype == torch.int32 and table.is_contiguous()
+        logits = torch.empty(n_tiles * TILE, dtype=torch.float32, device=pts.device)
+        wo = self.fc_out.weight.detach().reshape(-1).contiguous()
+        bo = self._fc_out_bias()
+        with torch.cuda.device(pts.device):
+            rc = _lib.lib().rfd_occ_decode(n_tiles, pts.data_ptr(), tile_prop.data_ptr(),
+                                           packed.data_ptr(), fc_p_w.data_ptr(), table.data_ptr(),
+                                           wo.data_ptr(), bo, logits.data_ptr(),
+                                           self.mode if mode is None else mode,
+                                           _lib.current_stream())
+        _lib.check(rc, "rfd_occ_decode")
+        return logits
+
+    def forward(self, p, z, c, **kwargs):
+        """p (B,T,3), z (B,Z), c (B,C) -> logits (B,T).  occ_decoder.py:110-123."""
+        if not p.is_cuda:
+            raise RuntimeError("CPU not supported")
+        B, T, _ = p.shape
+        if c.dim() == 3:
+            c = c.squeeze(2)
+        table, fc_p_w = self.fold(z.float(), c.float())
+        tpad = (T + TILE - 1) // TILE * TILE
+        if tpad != T:
+            pp = torch.zeros(B, tpad, 3, dtype=torch.float32, device=p.device)
+            pp[:, :T] = p
+        else:
+            pp = p.contiguous().float()
+        tiles_per = tpad // TILE
+        tile_prop = torch.arange(B, dtype=torch.int32, device=p.device).repeat_interleave(tiles_per)
+        logits = self.decode_tiles(pp.reshape(-1, 3), tile_prop, table, fc_p_w)
+        return logits.view(B, tpad)[:, :T]

@@ -1,0 +1,88 @@
+"""GPU (-m gpu): fused occupancy decoder vs the oracle / reference fixture.
+Tolerance: 1e-4 absolute on logits (BASELINE.json north_star)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from rfdnet_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-4
+
+
+def seeded_decoder(seed=1234):
+    from rfdnet_amd.iscnet.occ_decoder import DecoderCBatchNorm
+    dec = DecoderCBatchNorm(dim=3, z_dim=32, c_dim=512, hidden_size=256)
+    synthetic.load_seeded(dec, seed)
+    return dec.cuda().eval()
+
+
+def test_decoder_matches_reference_fixture(hip, golden_dir):
+    """F-DEC: logits of the reference DecoderCBatchNorm (torch CPU fp32)."""
+    fx = np.load(os.path.join(golden_dir, "F_DEC.npz"))
+    dec = seeded_decoder(int(fx["seed"]))
+    with torch.no_grad():
+        out = dec(torch.from_numpy(fx["p"]).cuda(), torch.from_numpy(fx["z"]).cuda(),
+                  torch.from_numpy(fx["c"]).cuda())
+    hip.device_status()
+    err = np.abs(out.cpu().numpy() - fx["logits"]).max()
+    assert err < LOGIT_TOL, err
+    assert err < 2e-5, err            # the parity mode is fp32-class, not just in tolerance
+
+
+def test_decoder_matches_oracle_ragged(hip, oracle):
+    """T not a multiple of the 128-point tile, several proposals, non-zero z"""
+    dec = seeded_decoder(99)
+    sd = OrderedDict((k, v.detach().cpu().numpy()) for k, v in dec.state_dict().items())
+    blob = oracle.decoder_param_blob(sd)
+    rng = np.random.default_rng(5)
+    K, T = 5, 333
+    p = ((rng.random((K, T, 3)) - 0.5) * 1.1).astype(np.float32)
+    z = rng.normal(0, 1, (K, 32)).astype(np.float32)
+    c = rng.normal(0, 1, (K, 512)).astype(np.float32)
+    ref = oracle.decoder_cbn(blob, p, z, c)
+    with torch.no_grad():
+        out = dec(torch.from_numpy(p).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(c).cuda())
+    hip.device_status()
+    assert np.abs(out.cpu().numpy() - ref).max() < LOGIT_TOL
+
+
+def test_decoder_throughput_mode_error_is_reported_not_hidden(hip, golden_dir):
+    from rfdnet_amd.iscnet import occ_decoder
+    fx = np.load(os.path.join(golden_dir, "F_DEC.npz"))
+    dec = seeded_decoder(int(fx["seed"]))
+    dec.mode = occ_decoder.MODE_F16X1
+    with torch.no_grad():
+        out = dec(torch.from_numpy(fx["p"]).cuda(), torch.from_numpy(fx["z"]).cuda(),
+                  torch.from_numpy(fx["c"]).cuda())
+    err = np.abs(out.cpu().numpy() - fx["logits"]).max()
+    assert err < 5e-3, err           # f16x1 is NOT the parity mode
+    sign = ((out.cpu().numpy() > 0) == (fx["logits"] > 0)).mean()
+    assert sign > 0.995
+
+
+def test_decoder_point_independence(hip):
+    """a point's logit must not depend on its tile neighbours / position"""
+    dec = seeded_decoder(7)
+    rng = np.random.default_rng(1)
+    p = ((rng.random((1, 512, 3)) - 0.5)).astype(np.float32)
+    z = np.zeros((1, 32), np.float32)
+    c = rng.normal(0, 1, (1, 512)).astype(np.float32)
+    with torch.no_grad():
+        a = dec(torch.from_numpy(p).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(c).cuda())
+        perm = rng.permutation(512)
+        b = dec(torch.from_numpy(p[:, perm]).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(c).cuda())
+    np.testing.assert_array_equal(a.cpu().numpy()[0][perm], b.cpu().numpy()[0])
+
+
+def test_decoder_flags_f16_overflow(hip):
+    dec = seeded_decoder(7)
+    with torch.no_grad():
+        dec.blocks[0].bn_0.conv_beta.bias.fill_(5000.0)      # activations ~5000 * 2^6 > f16 max
+        p = torch.zeros(1, 128, 3).cuda()
+        dec(p, torch.zeros(1, 32).cuda(), torch.zeros(1, 512).cuda())
+    with pytest.raises(hip.RfdHipError, match="f16 range"):
+        hip.device_status()

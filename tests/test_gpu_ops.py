@@ -1,0 +1,218 @@
+"""GPU (-m gpu): the HIP point ops, called through the C ABI (via the
+`pointnet2_ops._ext` boundary), against the CPU oracle on the same seeded
+inputs.  Bit-exact for indices AND for the float outputs (pure copies or a
+fixed fma order)."""
+import numpy as np
+import pytest
+import torch
+
+from rfdnet_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def scene(rng, n, dup=0, origin=0, lo=-2, hi=2):
+    p = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    if dup:
+        p[rng.integers(0, n, dup)] = p[rng.integers(0, n, dup)]
+    if origin:
+        p[rng.integers(0, n, origin)] = rng.uniform(-0.01, 0.01, (origin, 3)).astype(np.float32)
+    return p
+
+
+@pytest.fixture(scope="module")
+def ext(hip):
+    from rfdnet_amd.pointnet2_ops import _ext
+    return _ext
+
+
+# ---------------------------------------------------------------- FPS ---------
+@pytest.mark.parametrize("b,n,m,dup,origin", [
+    (1, 1, 1, 0, 0), (1, 3, 3, 0, 0), (2, 37, 11, 0, 0), (1, 64, 64, 0, 0),
+    (2, 512, 256, 40, 5), (1, 1024, 512, 100, 8), (3, 2048, 1024, 300, 16),
+    (1, 4096, 1000, 500, 16),                      # single workgroup, 16 pts/thread
+    (1, 4097, 300, 100, 4), (2, 10000, 700, 2000, 16),   # multi-workgroup exchange
+    (1, 40000, 512, 10000, 16),
+])
+def test_fps_bit_exact(ext, oracle, hip, b, n, m, dup, origin):
+    rng = np.random.default_rng(n * 31 + m)
+    p = np.stack([scene(rng, n, dup, origin) for _ in range(b)])
+    ref = oracle.furthest_point_sampling(p, m)
+    out = ext.furthest_point_sampling(dev(p), m)
+    hip.device_status()
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_fps_config2_scene_80k(ext, oracle, hip):
+    """BASELINE config 2: 80 000 points -> 2048 samples, synthetic ScanNet-like
+    scene with duplicated and near-origin points; indices AND the temp scratch."""
+    pc = synthetic.synthetic_scene(seed=10, n_points=80000)
+    p = pc[None, :, :3].copy()
+    ref, rtemp = oracle.furthest_point_sampling(p, 2048, return_temp=True)
+    x = dev(p)
+    tmp = torch.empty(1, 80000, device="cuda")
+    out = torch.zeros(1, 2048, dtype=torch.int32, device="cuda")
+    rc = hip.lib().furthest_point_sampling_kernel_wrapper(1, 80000, 2048, x.data_ptr(), tmp.data_ptr(),
+                                                          out.data_ptr(), hip.current_stream())
+    hip.check(rc, "fps")
+    hip.device_status()
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    np.testing.assert_array_equal(tmp.cpu().numpy(), rtemp)
+
+
+def test_fps_lattice_ties(ext, oracle):
+    g = np.stack(np.meshgrid(*[np.arange(17)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    p = (g[np.random.default_rng(5).permutation(g.shape[0])] + 1.0).astype(np.float32)[None]
+    np.testing.assert_array_equal(ext.furthest_point_sampling(dev(p), 600).cpu().numpy(),
+                                  oracle.furthest_point_sampling(p, 600))
+
+
+def test_fps_all_skipped_and_with_replacement_scene(ext, oracle):
+    p = np.random.default_rng(0).uniform(-0.01, 0.01, (1, 300, 3)).astype(np.float32)
+    assert (ext.furthest_point_sampling(dev(p), 20).cpu().numpy() == 0).all()
+    pc = synthetic.synthetic_scene(seed=11, n_raw=30000, n_points=40000)   # config-1 style duplicates
+    p = pc[None, :, :3].copy()
+    np.testing.assert_array_equal(ext.furthest_point_sampling(dev(p), 256).cpu().numpy(),
+                                  oracle.furthest_point_sampling(p, 256))
+
+
+def test_fps_gather_fused(ext, oracle):
+    rng = np.random.default_rng(2)
+    p = np.stack([scene(rng, 5000, 50, 4) for _ in range(2)])
+    idx, new_xyz = ext.furthest_point_sampling_gather(dev(p), 128)
+    ref = oracle.furthest_point_sampling(p, 128)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(new_xyz.cpu().numpy(), np.stack([p[i][ref[i]] for i in range(2)]))
+
+
+def test_fps_idempotent_on_fps_ordered_prefix(ext):
+    """pointnet2backbone.py:104,124 relies on FPS of an FPS-ordered set returning 0..m-1"""
+    pc = synthetic.synthetic_scene(seed=10, n_points=20000, with_origin_pts=False)
+    x = dev(pc[None, :, :3].copy())
+    i1 = ext.furthest_point_sampling(x, 1024)
+    sub = torch.gather(x, 1, i1.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    i2 = ext.furthest_point_sampling(sub, 512)
+    np.testing.assert_array_equal(i2.cpu().numpy()[0], np.arange(512))
+
+
+# --------------------------------------------------------- ball query ---------
+@pytest.mark.parametrize("b,n,m,ns,r", [
+    (1, 1, 1, 4, 1.0), (2, 300, 20, 8, 0.5), (1, 1000, 64, 16, 0.3), (2, 257, 33, 64, 4.0),
+    (1, 128, 16, 4, 0.01), (1, 5000, 3000, 32, 0.4), (2, 2048, 1024, 32, 0.4),
+    (1, 6000, 7, 1024, 1.0),
+])
+def test_ball_query_bit_exact(ext, oracle, b, n, m, ns, r):
+    rng = np.random.default_rng(n + m + ns)
+    xyz = np.stack([scene(rng, n, dup=n // 10) for _ in range(b)])
+    new = np.stack([np.concatenate([xyz[i][rng.integers(0, n, max(m - 1, 0))],
+                                    np.array([[50, 50, 50]], dtype=np.float32)])[:m] for i in range(b)])
+    ref = oracle.ball_query(new, xyz, r, ns)
+    out = ext.ball_query(dev(new), dev(xyz), r, ns)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_ball_query_config2_sa1(ext, oracle):
+    """SA1 of config 2: 2048 centres x 80 000 points, ns=64, r=0.2"""
+    pc = synthetic.synthetic_scene(seed=10, n_points=80000)
+    xyz = pc[None, :, :3].copy()
+    inds = oracle.furthest_point_sampling(xyz[:, :20000], 2048)     # any spread centre set
+    new = xyz[:, inds[0]]
+    ref = oracle.ball_query(new, xyz, 0.2, 64)
+    out = ext.ball_query(dev(new), dev(xyz), 0.2, 64)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # properties at full size: ascending prefix, all within r, padded with the first hit
+    o = out.cpu().numpy()[0]
+    d2 = ((xyz[0][o] - new[0][:, None, :]) ** 2).sum(-1)
+    assert (d2 < 0.2 ** 2 + 1e-6).all()
+
+
+def test_ball_query_skip_propagation_shape(ext, oracle):
+    """skip_propagation.py:26-31: K centres x 80 000 points, r=1.0, ns=1024"""
+    pc = synthetic.synthetic_scene(seed=10, n_points=80000)
+    xyz = pc[None, :, :3].copy()
+    rng = np.random.default_rng(1)
+    new = (xyz[:, rng.integers(0, 80000, 24)] + np.float32(0.05)).astype(np.float32)
+    np.testing.assert_array_equal(ext.ball_query(dev(new), dev(xyz), 1.0, 1024).cpu().numpy(),
+                                  oracle.ball_query(new, xyz, 1.0, 1024))
+
+
+# --------------------------------------------------- group / gather / interp ---
+@pytest.mark.parametrize("b,c,n,m,ns", [(1, 1, 5, 3, 2), (2, 4, 4000, 512, 64), (1, 131, 2048, 1024, 32),
+                                        (2, 259, 512, 256, 16), (1, 5, 80000, 16, 1024)])
+def test_group_points_bit_exact(ext, oracle, b, c, n, m, ns):
+    rng = np.random.default_rng(c + n)
+    pts = rng.normal(size=(b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    np.testing.assert_array_equal(ext.group_points(dev(pts), dev(idx)).cpu().numpy(),
+                                  oracle.group_points(pts, idx))
+
+
+def test_gather_points_bit_exact(ext, oracle):
+    rng = np.random.default_rng(4)
+    pts = rng.normal(size=(2, 3, 80000)).astype(np.float32)
+    idx = rng.integers(0, 80000, (2, 2048)).astype(np.int32)
+    np.testing.assert_array_equal(ext.gather_points(dev(pts), dev(idx)).cpu().numpy(),
+                                  oracle.gather_points(pts, idx))
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (1, 5, 2), (2, 512, 256), (1, 1024, 512), (1, 700, 1500)])
+def test_three_nn_bit_exact(ext, oracle, b, n, m):
+    rng = np.random.default_rng(n + m)
+    u = np.stack([scene(rng, n) for _ in range(b)])
+    k = np.stack([scene(rng, m, dup=m // 5) for _ in range(b)])
+    d2, idx = ext.three_nn(dev(u), dev(k))
+    rd2, ridx = oracle.three_nn(u, k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(d2.cpu().numpy(), rd2)
+
+
+@pytest.mark.parametrize("b,c,m,n", [(1, 1, 3, 2), (2, 256, 256, 512), (1, 256, 512, 1024)])
+def test_three_interpolate_bit_exact(ext, oracle, b, c, m, n):
+    rng = np.random.default_rng(c + m)
+    pts = rng.normal(size=(b, c, m)).astype(np.float32)
+    idx = rng.integers(0, m, (b, n, 3)).astype(np.int32)
+    w = rng.random((b, n, 3)).astype(np.float32)
+    np.testing.assert_array_equal(ext.three_interpolate(dev(pts), dev(idx), dev(w)).cpu().numpy(),
+                                  oracle.three_interpolate(pts, idx, w))
+
+
+def test_grad_ops_match_oracle(ext, oracle):
+    rng = np.random.default_rng(8)
+    b, c, n, m, ns = 2, 7, 300, 40, 8
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    go = rng.normal(size=(b, c, m, ns)).astype(np.float32)
+    np.testing.assert_allclose(ext.group_points_grad(dev(go), dev(idx), n).cpu().numpy(),
+                               oracle.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+    gi = rng.integers(0, n, (b, m)).astype(np.int32)
+    go2 = rng.normal(size=(b, c, m)).astype(np.float32)
+    np.testing.assert_allclose(ext.gather_points_grad(dev(go2), dev(gi), n).cpu().numpy(),
+                               oracle.gather_points_grad(go2, gi, n), rtol=1e-5, atol=1e-5)
+    i3 = rng.integers(0, n, (b, m, 3)).astype(np.int32)
+    w = rng.random((b, m, 3)).astype(np.float32)
+    np.testing.assert_allclose(ext.three_interpolate_grad(dev(go2), dev(i3), dev(w), n).cpu().numpy(),
+                               oracle.three_interpolate_grad(go2, i3, w, n), rtol=1e-5, atol=1e-5)
+
+
+def test_group_concat_equals_reference_composition(ext, oracle):
+    """fused QueryAndGroup epilogue == group(xyz^T) - centre, / radius, cat features
+    (pointnet2_utils.py:333-344), bit for bit"""
+    rng = np.random.default_rng(12)
+    b, c, n, m, ns, r = 2, 6, 3000, 200, 16, 0.37
+    xyz = np.stack([scene(rng, n) for _ in range(b)])
+    feats = rng.normal(size=(b, c, n)).astype(np.float32)
+    new = xyz[:, :m].copy()
+    idx = oracle.ball_query(new, xyz, r, ns)
+    gx = oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx)
+    gx = gx - new.transpose(0, 2, 1)[..., None]
+    gxn = (gx / np.float32(r)).astype(np.float32)
+    gf = oracle.group_points(feats, idx)
+    out, g = ext.group_concat(dev(xyz), dev(new), dev(feats), dev(idx), r, True, True, True)
+    np.testing.assert_array_equal(out.cpu().numpy(), np.concatenate([gxn, gf], 1))
+    np.testing.assert_array_equal(g.cpu().numpy(), gxn)
+    out2, g2 = ext.group_concat(dev(xyz), dev(new), dev(feats), dev(idx), r, False, False, True)
+    np.testing.assert_array_equal(out2.cpu().numpy(), gf)
+    np.testing.assert_array_equal(g2.cpu().numpy(), gx)
