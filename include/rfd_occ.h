@@ -63,7 +63,10 @@ int rfd_occ_pack_weights(const float *fc0_w, const float *fc1_w,
 /* Decode n_tiles tiles of RFD_OCC_TILE query points.
  *  pts        [n_tiles*128][3] fp32 query points (pad the tail of a
  *             proposal's last tile with anything; those logits are garbage)
- *  tile_prop  [n_tiles] int32: proposal index of each tile
+ *  tile_prop  [n_tiles] int32: proposal index of each tile (< 0: skip tile)
+ *  tile_src   [n_tiles] int32 or NULL: tile t reads its 128 points from
+ *             pts[tile_src[t]*128 ...] (NULL = identity); lets all proposals
+ *             share one copy of a dense grid
  *  packed     weight stream from rfd_occ_pack_weights
  *  fc_p_w     [256][3] fp32 = fc_p.weight * 2^KH   (KH = ka + kw1)
  *  table      [K][23][256] fp32 per-proposal folded table (rfd_occ_fold.py /
@@ -74,9 +77,76 @@ int rfd_occ_pack_weights(const float *fc0_w, const float *fc1_w,
  *  logits     [n_tiles*128] fp32 out
  *  mode       RFD_OCC_MODE_* */
 int rfd_occ_decode(int n_tiles, const float *pts, const int *tile_prop,
-                   const void *packed, const float *fc_p_w, const float *table,
+                   const int *tile_src, const void *packed, const float *fc_p_w, const float *table,
                    const float *fc_out_w, float fc_out_b, float *logits,
                    int mode, void *stream);
+
+/* ---- query-point generators ---------------------------------------------------
+ * Dense path (generator.py:91-97): pts[n^3][3] = scale * make_3d_grid(lo, hi, n)
+ * (external/common.py:157-176: torch.linspace inclusive of both ends, x-major
+ * flattening; linspace evaluated as start + step*i for i < n/2 and
+ * end - step*(n-1-i) otherwise, the torch GPU kernel's formula).  The array is
+ * padded with zeros up to a multiple of RFD_OCC_TILE points (n_padded). */
+int rfd_make_grid_points(int n, float lo, float hi, float scale, float *pts,
+                         int n_padded, void *stream);
+
+/* ---- batched MISE (external/libmise/mise.pyx:33-369) ----------------------------
+ * The reference keeps an octree (vector<Voxel>) and a hashed point list per
+ * proposal on the CPU and is driven one proposal at a time.  Here the state of
+ * ALL K proposals is dense and device-resident, and one launch advances every
+ * proposal by one round:
+ *   values [K][(R+1)^3] f32     grid values (R = resolution_0 << depth)
+ *   pstate [K][(R+1)^3] u8      0 no grid point | 1 exists, unknown | 2 known
+ *                               | 3 filled by to_dense
+ *   vstate [K][sum_{l<depth} (resolution_0 << l)^3] u8
+ *                               0 absent | 1 leaf | 2 subdivided
+ * Query order is irrelevant to the result (values are scattered back by
+ * lattice index), so points are handed out in whatever order the atomics give.
+ */
+size_t rfd_mise_vstate_elems(int res0, int depth);          /* per proposal */
+int rfd_mise_init(int K, int res0, int depth, unsigned char *pstate,
+                  unsigned char *vstate, void *stream);
+/* counts[k] = number of existing-but-unknown grid points (mise.pyx:111-114) */
+int rfd_mise_count(int K, int res0, int depth, const unsigned char *pstate,
+                   int *counts, void *stream);
+/* Write each proposal's unknown points into its tile-aligned segment:
+ * offsets[k] = first point slot of proposal k (multiple of 128), cursors[k]
+ * zero-initialised scratch.  pts[slot] = box_size * (c / R - 0.5)
+ * (generator.py:106-109), lin[slot] = lattice index.  Padding slots must be
+ * pre-set by the caller (lin = -1). */
+int rfd_mise_collect(int K, int res0, int depth, const unsigned char *pstate,
+                     const int *offsets, int *cursors, float box_size,
+                     float *pts, int *lin, void *stream);
+/* values[prop][lin] = logits[slot], pstate = known (mise.pyx:96-102) */
+int rfd_mise_scatter(int n_tiles, int res0, int depth, const int *tile_prop,
+                     const int *lin, const float *logits, float *values,
+                     unsigned char *pstate, void *stream);
+/* One subdivide_voxels pass (mise.pyx:196-251): a leaf voxel below max depth
+ * splits iff among the known points of its closed cube one has value >= thr
+ * and one has value <= thr (both non-strict, :225-227). */
+int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
+                       const float *values, unsigned char *pstate,
+                       unsigned char *vstate, void *stream);
+/* to_dense (mise.pyx:133-163): forward-fill along x, then y, then z. */
+int rfd_mise_to_dense(int K, int res0, int depth, float *values,
+                      unsigned char *pstate, void *stream);
+
+/* ---- batched marching cubes (generator.py:157-161; PyMCubes 0.1.2 is not
+ * vendored: published algorithm restated, ordering is ours) ----------------------
+ * grids [K][n][n][n] f32; the -1e6 padding shell of generator.py:158-159 is
+ * virtual: D = n + 2 lattice points per axis.  classify fills ebits[K][D^3]
+ * (crossed +x/+y/+z edges of each lattice point), vcount / tcount [K][D^3]
+ * (vertices owned by the point / triangles of the cell).  The caller takes
+ * EXCLUSIVE prefix sums vbase / tbase of the flattened count arrays, sizes the
+ * outputs, then emit writes verts [NV][3] f64 in padded-grid index coordinates
+ * (original grid point i sits at i + 1) and tris [NT][3] i32 with vertex
+ * indices local to each proposal.  Corner c is "outside" when value < iso;
+ * triangle normals point outside. */
+int rfd_mc_classify(int K, int n, float pad_value, double iso, const float *grids,
+                    unsigned char *ebits, int *vcount, int *tcount, void *stream);
+int rfd_mc_emit(int K, int n, float pad_value, double iso, const float *grids,
+                const unsigned char *ebits, const int *vbase, const int *tcount,
+                const int *tbase, double *verts, int *tris, void *stream);
 
 #ifdef __cplusplus
 }

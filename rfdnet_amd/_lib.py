@@ -28,7 +28,16 @@ SIGNATURES = {
     "rfd_group_concat": [_i, _i, _i, _i, _i, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f],
     "rfd_furthest_point_sampling_gather": [_i, _i, _i, _f, _f, _f, _f, _f],
     "rfd_occ_pack_weights": [_f, _f, C.POINTER(C.c_int), _i, _f, _f],
-    "rfd_occ_decode": [_i, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],
+    "rfd_occ_decode": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],
+    "rfd_make_grid_points": [_i, _fl, _fl, _fl, _f, _i, _f],
+    "rfd_mise_init": [_i, _i, _i, _f, _f, _f],
+    "rfd_mise_count": [_i, _i, _i, _f, _f, _f],
+    "rfd_mise_collect": [_i, _i, _i, _f, _f, _f, _fl, _f, _f, _f],
+    "rfd_mise_scatter": [_i, _i, _i, _f, _f, _f, _f, _f, _f],
+    "rfd_mise_subdivide": [_i, _i, _i, C.c_double, _f, _f, _f, _f],
+    "rfd_mise_to_dense": [_i, _i, _i, _f, _f, _f],
+    "rfd_mc_classify": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f],
+    "rfd_mc_emit": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f, _f, _f, _f],
 }
 _RESTYPES = {
     "rfd_last_error_string": C.c_char_p,
@@ -36,6 +45,7 @@ _RESTYPES = {
     "rfd_device_status": C.c_int,
     "rfd_occ_packed_bytes": C.c_size_t,
 }
+_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i]}
 
 _lib = None
 
@@ -52,6 +62,12 @@ def lib():
             raise RfdHipError(
                 "librfd_hip.so not built (%s). Run `python -m rfdnet_amd.build` "
                 "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must
+        # be in the process BEFORE our library is loaded so the dynamic loader
+        # resolves our DT_NEEDED libamdhip64 to that same copy: two HIP
+        # runtimes in one process cannot share device pointers or streams (the
+        # second one reports "no ROCm-capable device").
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)
@@ -61,12 +77,16 @@ def lib():
             fn = getattr(l, name)
             fn.restype = rt
             fn.argtypes = []
+        for name, at in _SIZE_FNS.items():
+            fn = getattr(l, name)
+            fn.restype = C.c_size_t
+            fn.argtypes = at
         _lib = l
     return _lib
 
 
 def exported_symbols():
-    return sorted(list(SIGNATURES) + list(_RESTYPES))
+    return sorted(list(SIGNATURES) + list(_RESTYPES) + list(_SIZE_FNS))
 
 
 def check(rc, what):

@@ -1,0 +1,301 @@
+// mise.hip -- batched multiresolution iso-surface extraction state machine and
+// dense query-grid generation for gfx950.
+//
+// Replaces external/libmise/mise.pyx:33-369 (Cython octree, one proposal at a
+// time on the CPU, std::map point hash) and the query-point arithmetic of
+// Generator3D.generate_from_latent (models/iscnet/modules/generator.py:91-115)
+// and make_3d_grid (external/common.py:157-176).
+//
+// MI355X-first restatement: the state of all K proposals is dense in HBM
+// (a byte per lattice point, a byte per octree voxel per level, 4 B per value),
+// one launch advances every proposal by one round, and nothing crosses PCIe
+// except one 4-byte "points left" counter per round.  These kernels are pure
+// byte/flag traffic: HBM-bound, coalesced along z (the fastest lattice axis).
+//
+// Equivalence with the octree (argued in DESIGN.md "MISE"): a leaf voxel V of
+// size s is marked by exactly the known grid points of its closed cube
+// [lo, lo+s]^3 (mise.pyx:205-228 marks, for every known point, the leaf that
+// contains each of the 8 unit cells around it), marking is complete before any
+// subdivision (:230-251) and children created in a pass are not examined in
+// that pass -- reproduced by processing levels from fine to coarse.
+#include "common.h"
+#include "../../include/rfd_occ.h"
+
+namespace {
+
+__host__ __device__ inline size_t cube(size_t n) { return n * n * n; }
+
+// offset (in elements) of level l inside a proposal's vstate block
+__host__ __device__ inline size_t vstate_offset(int res0, int l) {
+  size_t o = 0;
+  for (int i = 0; i < l; ++i) o += cube((size_t)res0 << i);
+  return o;
+}
+
+__global__ void grid_points_kernel(int n, float lo, float hi, float scale,
+                                   float *__restrict__ pts, int n_padded) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_padded) return;
+  const int total = n * n * n;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (e < total) {
+    const int k = e % n, j = (e / n) % n, i = e / (n * n);
+    const float step = n > 1 ? (hi - lo) / (float)(n - 1) : 0.f;
+    const int half = n / 2;
+    // torch.linspace (GPU formula): symmetric evaluation from both ends
+    auto ax = [&](int q) { return q < half ? lo + step * (float)q : hi - step * (float)(n - 1 - q); };
+    x = scale * ax(i);  // box_size * grid (generator.py:92-94)
+    y = scale * ax(j);
+    z = scale * ax(k);
+  }
+  pts[(size_t)e * 3 + 0] = x;
+  pts[(size_t)e * 3 + 1] = y;
+  pts[(size_t)e * 3 + 2] = z;
+}
+
+// pstate: 1 on the level-0 lattice (multiples of 2^depth), else 0 (mise.pyx:72-85)
+__global__ void mise_init_points_kernel(int R1, int vs0, size_t n_per,
+                                        unsigned char *__restrict__ pstate) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_per) return;
+  const int k = (int)(e % R1), j = (int)((e / R1) % R1), i = (int)(e / ((size_t)R1 * R1));
+  const unsigned char v = ((i % vs0) == 0 && (j % vs0) == 0 && (k % vs0) == 0) ? 1 : 0;
+  pstate[(size_t)blockIdx.y * n_per + e] = v;
+}
+
+__global__ void mise_init_voxels_kernel(size_t n0, size_t n_per,
+                                        unsigned char *__restrict__ vstate) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_per) return;
+  vstate[(size_t)blockIdx.y * n_per + e] = e < n0 ? 1 : 0;  // level 0: all leaves
+}
+
+__global__ void mise_count_kernel(size_t n_per, const unsigned char *__restrict__ pstate,
+                                  int *__restrict__ counts) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  int c = 0;
+  if (e < n_per) c = pstate[(size_t)k * n_per + e] == 1;
+  // wave-level reduction, one atomic per wave
+  const unsigned long long m = __ballot(c);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(counts + k, __popcll(m));
+}
+
+__global__ void mise_collect_kernel(int R1, size_t n_per,
+                                    const unsigned char *__restrict__ pstate,
+                                    const int *__restrict__ offsets,
+                                    int *__restrict__ cursors, float box_size,
+                                    float *__restrict__ pts, int *__restrict__ lin) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  const bool want = e < n_per && pstate[(size_t)k * n_per + e] == 1;
+  const unsigned long long m = __ballot(want);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(cursors + k, __popcll(m));
+  base = __shfl(base, 0);
+  if (!want) return;
+  const int slot = offsets[k] + base + __popcll(m & ((1ull << lane) - 1ull));
+  const int kz = (int)(e % R1), jy = (int)((e / R1) % R1), ix = (int)(e / ((size_t)R1 * R1));
+  const float res = (float)(R1 - 1);
+  // pointsf = points / resolution; box_size * (pointsf - 0.5)  (generator.py:106-109)
+  pts[(size_t)slot * 3 + 0] = box_size * ((float)ix / res - 0.5f);
+  pts[(size_t)slot * 3 + 1] = box_size * ((float)jy / res - 0.5f);
+  pts[(size_t)slot * 3 + 2] = box_size * ((float)kz / res - 0.5f);
+  lin[slot] = (int)e;
+}
+
+__global__ void mise_scatter_kernel(size_t n_per, const int *__restrict__ tile_prop,
+                                    const int *__restrict__ lin,
+                                    const float *__restrict__ logits,
+                                    float *__restrict__ values,
+                                    unsigned char *__restrict__ pstate) {
+  const int tile = blockIdx.x;
+  const int k = tile_prop[tile];
+  if (k < 0) return;
+  const size_t slot = (size_t)tile * RFD_OCC_TILE + threadIdx.x;
+  const int l = lin[slot];
+  if (l < 0) return;
+  values[(size_t)k * n_per + l] = logits[slot];  // mise.pyx:101
+  pstate[(size_t)k * n_per + l] = 2;             // :102 known = True
+}
+
+// One level of subdivide_voxels.  Thread per voxel of level `l`.
+__global__ void mise_subdivide_kernel(int R1, int res0, int depth, int l, double thr,
+                                      size_t n_per, size_t v_per,
+                                      const float *__restrict__ values,
+                                      unsigned char *__restrict__ pstate,
+                                      unsigned char *__restrict__ vstate) {
+  const int nl = res0 << l;
+  const size_t nvox = cube((size_t)nl);
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nvox) return;
+  const int kp = blockIdx.y;
+  unsigned char *vs = vstate + (size_t)kp * v_per + vstate_offset(res0, l);
+  if (vs[e] != 1) return;  // not a leaf (mise.pyx:236,245)
+  const int s = 1 << (depth - l);
+  const int vk = (int)(e % nl), vj = (int)((e / nl) % nl), vi = (int)(e / ((size_t)nl * nl));
+  const int x0 = vi * s, y0 = vj * s, z0 = vk * s;
+  unsigned char *ps = pstate + (size_t)kp * n_per;
+  const float *vals = values + (size_t)kp * n_per;
+  bool pos = false, neg = false;
+  for (int a = 0; a <= s; ++a)
+    for (int b = 0; b <= s; ++b)
+      for (int c = 0; c <= s; ++c) {
+        const size_t p = ((size_t)(x0 + a) * R1 + (y0 + b)) * R1 + (z0 + c);
+        if (ps[p] == 2) {
+          const double v = (double)vals[p];
+          pos = pos || (v >= thr);  // :225
+          neg = neg || (v <= thr);  // :227
+        }
+      }
+  if (!(pos && neg)) return;
+  vs[e] = 2;  // subdivide_voxel (:253-283)
+  if (l + 1 < depth) {
+    unsigned char *vc = vstate + (size_t)kp * v_per + vstate_offset(res0, l + 1);
+    const int nc = nl * 2;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 2; ++c)
+          vc[((size_t)(2 * vi + a) * nc + (2 * vj + b)) * nc + (2 * vk + c)] = 1;
+  }
+  const int h = s >> 1;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b)
+      for (int c = 0; c < 3; ++c) {
+        const size_t p = ((size_t)(x0 + a * h) * R1 + (y0 + b * h)) * R1 + (z0 + c * h);
+        if (ps[p] == 0) ps[p] = 1;  // only add new grid points (:281-283)
+      }
+}
+
+// Forward fill along one axis (mise.pyx:142-163).  Thread per line.
+// axis 0: lines indexed by (j,k) run along i, etc.  `valid` = pstate >= 2.
+__global__ void mise_fill_kernel(int R1, int axis, size_t n_per, float *__restrict__ values,
+                                 unsigned char *__restrict__ pstate) {
+  const int line = blockIdx.x * blockDim.x + threadIdx.x;
+  if (line >= R1 * R1) return;
+  const int kp = blockIdx.y;
+  // choose the line->(u,v) mapping so that consecutive threads touch
+  // consecutive z where possible
+  const int u = line / R1, v = line % R1;
+  size_t stride, start;
+  if (axis == 0) { stride = (size_t)R1 * R1; start = (size_t)u * R1 + v; }        // (j=u,k=v)
+  else if (axis == 1) { stride = R1; start = (size_t)u * R1 * R1 + v; }           // (i=u,k=v)
+  else { stride = 1; start = ((size_t)u * R1 + v) * R1; }                         // (i=u,j=v)
+  float *vals = values + (size_t)kp * n_per;
+  unsigned char *ps = pstate + (size_t)kp * n_per;
+  bool prev_valid = ps[start] >= 2;
+  float prev = vals[start];
+  for (int q = 1; q < R1; ++q) {
+    const size_t p = start + (size_t)q * stride;
+    const bool valid = ps[p] >= 2;
+    if (!valid && prev_valid) {
+      vals[p] = prev;
+      ps[p] = 3;
+    }
+    const bool now_valid = valid || prev_valid;
+    prev = now_valid ? vals[p] : prev;
+    prev_valid = now_valid;
+  }
+}
+
+}  // namespace
+
+RFD_API int rfd_make_grid_points(int n, float lo, float hi, float scale, float *pts,
+                                 int n_padded, void *stream) {
+  if (n_padded <= 0) return 0;
+  hipLaunchKernelGGL(grid_points_kernel, dim3(ceil_div(n_padded, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, lo, hi, scale, pts, n_padded);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API size_t rfd_mise_vstate_elems(int res0, int depth) {
+  const size_t v = vstate_offset(res0, depth);
+  return v ? v : 1;
+}
+
+RFD_API int rfd_mise_init(int K, int res0, int depth, unsigned char *pstate,
+                          unsigned char *vstate, void *stream) {
+  if (K <= 0) return 0;
+  const int R1 = (res0 << depth) + 1;
+  const size_t n_per = cube((size_t)R1);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mise_init_points_kernel, dim3((unsigned)((n_per + 255) / 256), K), dim3(256),
+                     0, s, R1, 1 << depth, n_per, pstate);
+  RFD_CHECK_LAUNCH();
+  const size_t v_per = rfd_mise_vstate_elems(res0, depth);
+  hipLaunchKernelGGL(mise_init_voxels_kernel, dim3((unsigned)((v_per + 255) / 256), K), dim3(256),
+                     0, s, depth > 0 ? cube((size_t)res0) : 0, v_per, vstate);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API int rfd_mise_count(int K, int res0, int depth, const unsigned char *pstate,
+                           int *counts, void *stream) {
+  if (K <= 0) return 0;
+  const int R1 = (res0 << depth) + 1;
+  const size_t n_per = cube((size_t)R1);
+  hipStream_t s = (hipStream_t)stream;
+  RFD_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * K, s));
+  hipLaunchKernelGGL(mise_count_kernel, dim3((unsigned)((n_per + 255) / 256), K), dim3(256), 0, s,
+                     n_per, pstate, counts);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API int rfd_mise_collect(int K, int res0, int depth, const unsigned char *pstate,
+                             const int *offsets, int *cursors, float box_size,
+                             float *pts, int *lin, void *stream) {
+  if (K <= 0) return 0;
+  const int R1 = (res0 << depth) + 1;
+  const size_t n_per = cube((size_t)R1);
+  hipLaunchKernelGGL(mise_collect_kernel, dim3((unsigned)((n_per + 255) / 256), K), dim3(256), 0,
+                     (hipStream_t)stream, R1, n_per, pstate, offsets, cursors, box_size, pts, lin);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API int rfd_mise_scatter(int n_tiles, int res0, int depth, const int *tile_prop,
+                             const int *lin, const float *logits, float *values,
+                             unsigned char *pstate, void *stream) {
+  if (n_tiles <= 0) return 0;
+  const int R1 = (res0 << depth) + 1;
+  hipLaunchKernelGGL(mise_scatter_kernel, dim3(n_tiles), dim3(RFD_OCC_TILE), 0,
+                     (hipStream_t)stream, cube((size_t)R1), tile_prop, lin, logits, values, pstate);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
+                               const float *values, unsigned char *pstate,
+                               unsigned char *vstate, void *stream) {
+  if (K <= 0 || depth <= 0) return 0;
+  const int R1 = (res0 << depth) + 1;
+  const size_t n_per = cube((size_t)R1);
+  const size_t v_per = rfd_mise_vstate_elems(res0, depth);
+  // fine -> coarse: children created at level l+1 were already visited this
+  // round, so they cannot split until the next update (mise.pyx:239-251)
+  for (int l = depth - 1; l >= 0; --l) {
+    const size_t nvox = cube((size_t)res0 << l);
+    hipLaunchKernelGGL(mise_subdivide_kernel, dim3((unsigned)((nvox + 255) / 256), K), dim3(256), 0,
+                       (hipStream_t)stream, R1, res0, depth, l, threshold, n_per, v_per, values,
+                       pstate, vstate);
+    RFD_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+RFD_API int rfd_mise_to_dense(int K, int res0, int depth, float *values,
+                              unsigned char *pstate, void *stream) {
+  if (K <= 0) return 0;
+  const int R1 = (res0 << depth) + 1;
+  const size_t n_per = cube((size_t)R1);
+  for (int axis = 0; axis < 3; ++axis) {
+    hipLaunchKernelGGL(mise_fill_kernel, dim3(ceil_div(R1 * R1, 256), K), dim3(256), 0,
+                       (hipStream_t)stream, R1, axis, n_per, values, pstate);
+    RFD_CHECK_LAUNCH();
+  }
+  return 0;
+}

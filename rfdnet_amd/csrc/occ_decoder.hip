@@ -136,7 +136,7 @@ __device__ __forceinline__ void cbn_relu_split(const f32x16 &x, const float *s_r
 template <int TERMS>
 __global__ __launch_bounds__(256) void occ_decode_kernel(
     int n_tiles, const float *__restrict__ pts, const int *__restrict__ tile_prop,
-    const half8 *__restrict__ packed, const float *__restrict__ fc_p_w,
+    const int *__restrict__ tile_src, const half8 *__restrict__ packed, const float *__restrict__ fc_p_w,
     const float *__restrict__ table, const float *__restrict__ fc_out_w,
     float fc_out_b, float *__restrict__ logits, unsigned *status) {
   constexpr bool X3 = TERMS == 3;
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int half = lane >> 5, n = lane & 31;
   const int prop = tile_prop[tile];
+  if (prop < 0) return;  // padding tile (whole workgroup, before any barrier)
 
   {  // stage the per-proposal table + first/last layer weights
     const f32x4 *src = reinterpret_cast<const f32x4 *>(table + (size_t)prop * ROWS * H);
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
   __syncthreads();
 
   const size_t pidx = (size_t)tile * TILE + wave * 32 + n;
-  const float px = pts[pidx * 3 + 0], py = pts[pidx * 3 + 1], pz = pts[pidx * 3 + 2];
+  const size_t sidx = (size_t)(tile_src ? tile_src[tile] : tile) * TILE + wave * 32 + n;
+  const float px = pts[sidx * 3 + 0], py = pts[sidx * 3 + 1], pz = pts[sidx * 3 + 2];
 
   // ---- fc_p (+ fc_z bias): H' = (Wp p + bp + zb) 2^KH, in accumulator layout
   f32x16 Hs[8];
@@ -269,7 +271,7 @@ RFD_API int rfd_occ_pack_weights(const float *fc0_w, const float *fc1_w,
 }
 
 RFD_API int rfd_occ_decode(int n_tiles, const float *pts, const int *tile_prop,
-                           const void *packed, const float *fc_p_w,
+                           const int *tile_src, const void *packed, const float *fc_p_w,
                            const float *table, const float *fc_out_w,
                            float fc_out_b, float *logits, int mode,
                            void *stream) {
@@ -280,11 +282,11 @@ RFD_API int rfd_occ_decode(int n_tiles, const float *pts, const int *tile_prop,
   hipStream_t s = (hipStream_t)stream;
   if (mode == RFD_OCC_MODE_F16X3) {
     hipLaunchKernelGGL(occ_decode_kernel<3>, dim3(n_tiles), dim3(256), 0, s, n_tiles, pts,
-                       tile_prop, (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b,
+                       tile_prop, tile_src, (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b,
                        logits, ws->status);
   } else if (mode == RFD_OCC_MODE_F16X1) {
     hipLaunchKernelGGL(occ_decode_kernel<1>, dim3(n_tiles), dim3(256), 0, s, n_tiles, pts,
-                       tile_prop, (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b,
+                       tile_prop, tile_src, (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b,
                        logits, ws->status);
   } else {
     rfd_set_error("rfd_occ_decode: unknown mode", hipErrorInvalidValue);

@@ -1,0 +1,72 @@
+"""Minimal configuration objects carrying exactly the keys the hot-path modules
+read (values = configs/config_files/ISCNet_test.yaml; dataset constants =
+configs/scannet_config.py:11-25).  The reference's CONFIG class (logging, save
+dirs, CUDA_VISIBLE_DEVICES) is out of scope."""
+import copy
+
+import numpy as np
+
+DEFAULT_CONFIG = {
+    'method': 'ISCNet',
+    'seed': 10,
+    'mode': 'demo',
+    'data': {
+        'num_point': 80000, 'num_target': 256, 'vote_factor': 1,
+        'cluster_sampling': 'seed_fps', 'no_height': False,
+        'use_color_detection': False, 'use_color_completion': False,
+        'hidden_dim': 512, 'c_dim': 512, 'z_dim': 32, 'threshold': 0.5,
+        'use_cls_for_completion': False, 'skip_propagate': True,
+    },
+    'model': {
+        'backbone': {'method': 'Pointnet2Backbone', 'loss': 'Null'},
+        'voting': {'method': 'VotingModule', 'loss': 'Null'},
+        'detection': {'method': 'ProposalModule', 'loss': 'DetectionLoss'},
+        'skip_propagation': {'method': 'SkipPropagation', 'loss': 'Null'},
+        'completion': {'method': 'ONet', 'loss': 'ONet_Loss', 'weight': 0.005},
+    },
+    'test': {'phase': 'completion', 'batch_size': 1},
+    'demo': {'phase': 'completion'},
+    'generation': {
+        'generate_mesh': True, 'resolution_0': 32, 'upsampling_steps': 0,
+        'use_sampling': False, 'refinement_step': 0, 'simplify_nfaces': None,
+        'dump_threshold': 0.5, 'dump_results': True,
+    },
+}
+
+
+class ScannetConfig(object):
+    """configs/scannet_config.py:11-25: 8 classes, 12 heading bins, 8 size
+    clusters.  mean_size_arr is read from datasets/scannet/scannet_means.npz in
+    the reference; that file is data, not code, so a user passes it in
+    (`mean_size_arr=`); the default is a neutral placeholder (only box decoding
+    in parse_predictions, a 'next' row, consumes it)."""
+
+    def __init__(self, mean_size_arr=None):
+        self.num_class = 8
+        self.num_heading_bin = 12
+        self.num_size_cluster = 8
+        self.mean_size_arr = (np.asarray(mean_size_arr, dtype=np.float64) if mean_size_arr is not None
+                              else np.full((8, 3), 0.8))
+
+    def class2angle_cuda(self, pred_cls, residual, to_label_format=True):
+        """scannet_config.py:55-63"""
+        angle_per_class = 2 * np.pi / float(self.num_heading_bin)
+        angle = pred_cls.float() * angle_per_class + residual
+        if to_label_format:
+            angle = angle - 2 * np.pi * (angle > np.pi).float()
+        return angle
+
+
+class Config(object):
+    def __init__(self, overrides=None, mean_size_arr=None):
+        self.config = copy.deepcopy(DEFAULT_CONFIG)
+        for sect, kv in (overrides or {}).items():
+            if isinstance(kv, dict):
+                self.config.setdefault(sect, {}).update(kv)
+            else:
+                self.config[sect] = kv
+        self.dataset_config = ScannetConfig(mean_size_arr)
+        self.eval_config = {'dataset_config': self.dataset_config}
+
+    def log_string(self, s):
+        print(s)

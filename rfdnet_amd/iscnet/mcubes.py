@@ -1,0 +1,49 @@
+"""Batched marching cubes on the device (csrc/mcubes.hip): the counterpart of
+`mcubes.marching_cubes(np.pad(occ_hat, 1, 'constant', constant_values=-1e6),
+threshold)` in Generator3D.extract_mesh (generator.py:157-161), for all K
+proposals at once."""
+import torch
+
+from .. import _lib
+
+
+def _call(name, dev, *args):
+    with torch.cuda.device(dev):
+        rc = getattr(_lib.lib(), name)(*args, _lib.current_stream())
+    _lib.check(rc, name)
+
+
+@torch.no_grad()
+def marching_cubes_batch(grids, threshold, pad_value=-1e6):
+    """grids (K,n,n,n) f32 device tensor -> list of K (vertices (nv,3) f64,
+    faces (nt,3) i32) device tensors.  Vertex coordinates are in the index
+    space of the PADDED grid (original grid point i at i + 1)."""
+    assert grids.is_cuda and grids.dtype == torch.float32 and grids.dim() == 4
+    grids = grids.contiguous()
+    K, n = grids.shape[0], grids.shape[1]
+    assert grids.shape[2] == n and grids.shape[3] == n
+    dev = grids.device
+    D = n + 2
+    per = D * D * D
+    ebits = torch.empty(K * per, dtype=torch.uint8, device=dev)
+    vcount = torch.empty(K * per, dtype=torch.int32, device=dev)
+    tcount = torch.empty(K * per, dtype=torch.int32, device=dev)
+    _call("rfd_mc_classify", dev, K, n, float(pad_value), float(threshold), grids.data_ptr(),
+          ebits.data_ptr(), vcount.data_ptr(), tcount.data_ptr())
+    vinc = torch.cumsum(vcount, 0, dtype=torch.int32)
+    tinc = torch.cumsum(tcount, 0, dtype=torch.int32)
+    vbase = vinc - vcount
+    tbase = tinc - tcount
+    # per-proposal boundaries + totals: one small D2H copy
+    ends = torch.arange(1, K + 1, device=dev) * per - 1
+    bounds = torch.stack([vinc[ends], tinc[ends]]).cpu()
+    vend = [0] + bounds[0].tolist()
+    tend = [0] + bounds[1].tolist()
+    nv, nt = vend[-1], tend[-1]
+    verts = torch.empty(max(nv, 1), 3, dtype=torch.float64, device=dev)
+    tris = torch.empty(max(nt, 1), 3, dtype=torch.int32, device=dev)
+    if nv:
+        _call("rfd_mc_emit", dev, K, n, float(pad_value), float(threshold), grids.data_ptr(),
+              ebits.data_ptr(), vbase.data_ptr(), tcount.data_ptr(), tbase.data_ptr(),
+              verts.data_ptr(), tris.data_ptr())
+    return [(verts[vend[k]:vend[k + 1]], tris[tend[k]:tend[k + 1]]) for k in range(K)]

@@ -1,0 +1,126 @@
+"""ISCNet: sub-networks assembled by name from the config's `model:` block and
+the generation pipeline of the reference's demo / test drivers.
+
+  ISCNet.__init__   models/iscnet/modules/network.py:17-54 (phase -> attribute
+                    names backbone, voting, detection, skip_propagation,
+                    completion; classes looked up in MODULES)
+  ISCNet.generate   demo.py:200-276 `generate` / network.py:56-180 (minus the
+                    GT-dependent steps, which need datasets absent here)
+  load_weight       models/network.py:81-89 (strip `module.`, module-by-module,
+                    missing keys tolerated)
+
+Proposal selection.  The reference keeps proposals with objectness > 0.5 that
+survive the CPU 3-D NMS of parse_predictions (ap_helper.py:131-264, numpy +
+scipy Delaunay) -- a "next" row of the scope table.  Until that row is built the
+selection is either 'all' (every one of the num_target proposals; BASELINE
+configs 1-4 are quoted on "256 proposals") or 'objectness' (probability
+threshold only), both evaluated on the device.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import (occupancy_net, pointnet2backbone, proposal_module,  # noqa: F401  (register)
+               skip_propagation, vote_module)
+from .registers import METHODS, MODULES
+
+
+@METHODS.register_module
+class ISCNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        phase = cfg.config[cfg.config['mode']]['phase']
+        phase_names = []
+        if phase in ['detection']:
+            phase_names += ['backbone', 'voting', 'detection']
+        if phase in ['completion']:
+            phase_names += ['backbone', 'voting', 'detection', 'completion']
+            if cfg.config['data']['skip_propagate']:
+                phase_names += ['skip_propagation']
+        if not cfg.config.get('model') or not phase_names:
+            raise ModuleNotFoundError('No submodule found. Please check the phase name and model definition.')
+        for phase_name, net_spec in cfg.config['model'].items():
+            if phase_name not in phase_names:
+                continue
+            cls = MODULES.get(net_spec['method'])
+            if cls is None:
+                raise ModuleNotFoundError('unknown module %r' % net_spec['method'])
+            self.add_module(phase_name, cls(cfg, None))
+
+    def load_weight(self, pretrained_model):
+        """state_dict with the reference's key names (optionally `module.`-prefixed)."""
+        own = self.state_dict()
+        stripped = {'.'.join(k.split('.')[1:]) if k.startswith('module.') else k: v
+                    for k, v in pretrained_model.items()}
+        own.update({k: v for k, v in stripped.items() if k in own})
+        self.load_state_dict(own)
+
+    # ---------------------------------------------------------------- stages ---
+    def detect(self, point_clouds):
+        """backbone -> voting (+L2 norm) -> proposal  (demo.py:206-221)."""
+        end_points = self.backbone(point_clouds, {})
+        xyz, features = end_points['fp2_xyz'], end_points['fp2_features']
+        end_points['seed_inds'] = end_points['fp2_inds']
+        end_points['seed_xyz'] = xyz
+        end_points['seed_features'] = features
+        xyz, features = self.voting(xyz, features)
+        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+        end_points['vote_xyz'] = xyz
+        end_points['vote_features'] = features
+        end_points, proposal_features = self.detection(xyz, features, end_points, True)
+        return end_points, proposal_features
+
+    def select_proposals(self, end_points, selection='all'):
+        """-> (B, K, 1) int64 proposal ids (the layout of BATCH_PROPOSAL_IDs, demo.py:50-75)."""
+        B, P = end_points['center'].shape[0], end_points['center'].shape[1]
+        dev = end_points['center'].device
+        if selection == 'all':
+            return torch.arange(P, device=dev).view(1, P, 1).expand(B, P, 1).contiguous()
+        if selection == 'objectness':
+            assert B == 1
+            thr = self.cfg.config['generation']['dump_threshold']
+            prob = torch.softmax(end_points['objectness_scores'], dim=2)[..., 1]
+            ids = torch.nonzero(prob[0] > thr).view(1, -1, 1)
+            return ids
+        raise ValueError(selection)
+
+    def object_codes(self, end_points, proposal_features, ids, point_clouds):
+        """gather per-proposal features / centres / headings and run skip
+        propagation (demo.py:236-258) -> (B*K, c_dim)."""
+        dev = end_points['center'].device
+        idx = ids[..., 0]
+        feats = torch.gather(proposal_features, 2, idx.unsqueeze(1).expand(-1, 128, -1))
+        if not self.cfg.config['data']['skip_propagate']:
+            obj = feats
+        else:
+            centers = torch.gather(end_points['center'], 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+            dc = self.cfg.dataset_config
+            heading_class = torch.argmax(end_points['heading_scores'], -1)
+            residuals = end_points['heading_residuals_normalized'] * (np.pi / dc.num_heading_bin)
+            heading_residual = torch.gather(residuals, 2, heading_class.unsqueeze(-1)).squeeze(2)
+            angles = dc.class2angle_cuda(heading_class, heading_residual)
+            angles = torch.gather(angles, 1, idx)
+            obj = self.skip_propagation.generate(centers.contiguous(), angles, feats, point_clouds)
+        B, C, K = obj.size()
+        return obj.transpose(1, 2).contiguous().view(B * K, C)
+
+    def cls_codes(self, end_points, ids):
+        sem = end_points['sem_cls_scores']
+        g = torch.gather(sem, 1, ids[..., 0].unsqueeze(-1).expand(-1, -1, sem.size(2)))
+        one_hot = (g >= torch.max(g, dim=2, keepdim=True)[0]).float()
+        return one_hot.view(-1, sem.size(2))
+
+    @torch.no_grad()
+    def generate(self, data, selection='all', return_grids=False):
+        """data['point_clouds'] (B,N,3+f) -> (end_points, proposal ids, meshes)."""
+        pc = data['point_clouds']
+        end_points, proposal_features = self.detect(pc)
+        ids = self.select_proposals(end_points, selection)
+        codes = self.object_codes(end_points, proposal_features, ids, pc)
+        cls = self.cls_codes(end_points, ids)
+        gen = self.completion.generator
+        if return_grids:
+            return end_points, ids, gen.generate_grids(codes, cls)
+        meshes = gen.generate_mesh(codes, cls)
+        return end_points, ids, meshes

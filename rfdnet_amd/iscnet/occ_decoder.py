@@ -127,17 +127,20 @@ class DecoderCBatchNorm(nn.Module):
             sd["fc_z.bias"] = torch.zeros(256, device=c.device)
         return occ_fold.fold_table(sd, z, c, kw0, kw1)
 
-    def decode_tiles(self, pts, tile_prop, table, fc_p_w, mode=None):
-        """pts (n_tiles*128,3) f32, tile_prop (n_tiles,) i32 -> logits (n_tiles*128,)."""
+    def decode_tiles(self, pts, tile_prop, table, fc_p_w, mode=None, tile_src=None):
+        """pts (n_src_tiles*128,3) f32, tile_prop (n_tiles,) i32 [, tile_src
+        (n_tiles,) i32: which source tile each tile reads] -> logits (n_tiles*128,)."""
         packed, _, _ = self.packed_weights()
         n_tiles = tile_prop.shape[0]
-        assert pts.is_contiguous() and pts.shape[0] == n_tiles * TILE and pts.dtype == torch.float32
+        assert pts.is_contiguous() and pts.dtype == torch.float32
+        assert tile_src is not None or pts.shape[0] == n_tiles * TILE
         assert tile_prop.dtype == torch.int32 and table.is_contiguous()
         logits = torch.empty(n_tiles * TILE, dtype=torch.float32, device=pts.device)
         wo = self.fc_out.weight.detach().reshape(-1).contiguous()
         bo = self._fc_out_bias()
         with torch.cuda.device(pts.device):
             rc = _lib.lib().rfd_occ_decode(n_tiles, pts.data_ptr(), tile_prop.data_ptr(),
+                                           tile_src.data_ptr() if tile_src is not None else None,
                                            packed.data_ptr(), fc_p_w.data_ptr(), table.data_ptr(),
                                            wo.data_ptr(), bo, logits.data_ptr(),
                                            self.mode if mode is None else mode,

@@ -1,0 +1,111 @@
+"""PointNet segmentation net that masks the points of each proposal
+(models/iscnet/modules/pointseg.py).  Sub-module and parameter names follow the
+reference so its checkpoints load; dense 1x1 convolutions stay on rocBLAS."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class _TNet(nn.Module):
+    """Shared trunk of STN3d (:7-42) and STNkd (:45-79): k_in -> k_out*k_out."""
+
+    def __init__(self, k_in, k_out):
+        super().__init__()
+        self.conv1 = nn.Conv1d(k_in, 64, 1)
+        self.conv2 = nn.Conv1d(64, 128, 1)
+        self.conv3 = nn.Conv1d(128, 1024, 1)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, k_out * k_out)
+        self.relu = nn.ReLU()
+        self.bn1 = nn.BatchNorm1d(64)
+        self.bn2 = nn.BatchNorm1d(128)
+        self.bn3 = nn.BatchNorm1d(1024)
+        self.bn4 = nn.BatchNorm1d(512)
+        self.bn5 = nn.BatchNorm1d(256)
+        self._k_out = k_out
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = F.relu(self.bn3(self.conv3(x)))
+        x = torch.max(x, 2)[0]
+        x = F.relu(self.bn4(self.fc1(x)))
+        x = F.relu(self.bn5(self.fc2(x)))
+        x = self.fc3(x)
+        k = self._k_out
+        x = x + torch.eye(k, device=x.device, dtype=x.dtype).view(1, k * k)
+        return x.view(-1, k, k)
+
+
+class STN3d(_TNet):
+    def __init__(self, channel):
+        super().__init__(channel, 3)
+
+
+class STNkd(_TNet):
+    def __init__(self, k=64):
+        super().__init__(k, k)
+        self.k = k
+
+
+class PointNetEncoder(nn.Module):
+    def __init__(self, global_feat=True, feature_transform=False, channel=3):
+        super().__init__()
+        self.stn = STN3d(channel)
+        self.conv1 = nn.Conv1d(channel, 64, 1)
+        self.conv2 = nn.Conv1d(64, 128, 1)
+        self.conv3 = nn.Conv1d(128, 1024, 1)
+        self.bn1 = nn.BatchNorm1d(64)
+        self.bn2 = nn.BatchNorm1d(128)
+        self.bn3 = nn.BatchNorm1d(1024)
+        self.global_feat = global_feat
+        self.feature_transform = feature_transform
+        if feature_transform:
+            self.fstn = STNkd(k=64)
+
+    def forward(self, x):
+        B, D, N = x.size()
+        trans = self.stn(x)
+        x = x.transpose(2, 1)
+        if D > 3:
+            x = torch.cat([torch.bmm(x[..., :3], trans), x[..., 3:]], dim=2)
+        else:
+            x = torch.bmm(x, trans)
+        x = F.relu(self.bn1(self.conv1(x.transpose(2, 1))))
+        trans_feat = None
+        if self.feature_transform:
+            trans_feat = self.fstn(x)
+            x = torch.bmm(x.transpose(2, 1), trans_feat).transpose(2, 1)
+        pointfeat = x
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = self.bn3(self.conv3(x))
+        x = torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+        if self.global_feat:
+            return x, trans, trans_feat
+        x = x.view(-1, 1024, 1).repeat(1, 1, N)
+        return torch.cat([x, pointfeat], 1), trans, trans_feat
+
+
+class PointSeg(nn.Module):
+    def __init__(self, num_class, channel):
+        super().__init__()
+        self.k = num_class
+        self.feat = PointNetEncoder(global_feat=False, feature_transform=True, channel=channel)
+        self.conv1 = nn.Conv1d(1088, 512, 1)
+        self.conv2 = nn.Conv1d(512, 256, 1)
+        self.conv3 = nn.Conv1d(256, 128, 1)
+        self.conv4 = nn.Conv1d(128, self.k, 1)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.bn3 = nn.BatchNorm1d(128)
+
+    def forward(self, x):
+        B, _, n_pts = x.size()
+        x, _, trans_feat = self.feat(x)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = F.relu(self.bn3(self.conv3(x)))
+        x = self.conv4(x).transpose(2, 1).contiguous()
+        x = F.log_softmax(x.view(-1, self.k), dim=-1).view(B, n_pts, self.k)
+        return x, trans_feat

@@ -1,0 +1,48 @@
+"""Skip propagation (generation path): group scan points around each predicted
+box, align to the box frame, mask with PointSeg and encode to the shape code
+(models/iscnet/modules/skip_propagation.py:13-82).  The K x 80 000 ball query
+(r = 1 m, 1024 samples) and the grouping are HIP kernels; the dense nets are
+torch/rocBLAS."""
+import torch
+from torch import nn
+
+from ..pointnet2_ops.pointnet2_modules import STN_Group
+from .layers import ResnetPointnet
+from .pointseg import PointSeg
+from .registers import MODULES
+
+
+@MODULES.register_module
+class SkipPropagation(nn.Module):
+    def __init__(self, cfg, optim_spec=None):
+        super().__init__()
+        self.optim_spec = optim_spec
+        data = cfg.config['data']
+        self.input_feature_dim = int(data['use_color_completion']) * 3 + int(not data['no_height']) * 1
+        self.stn = STN_Group(radius=1., nsample=1024, use_xyz=False, normalize_xyz=True)
+        self.encoder = ResnetPointnet(c_dim=data['c_dim'], dim=self.input_feature_dim + 3 + 128,
+                                      hidden_dim=data['hidden_dim'])
+        self.point_seg = PointSeg(num_class=2, channel=self.input_feature_dim + 3)
+
+    def _break_up_pc(self, pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = (pc[..., 3:3 + self.input_feature_dim].transpose(1, 2).contiguous()
+                    if pc.size(-1) > 3 else None)
+        return xyz, features
+
+    def generate(self, box_xyz, box_orientations, box_feature, input_point_cloud):
+        """box_xyz (B,K,3), box_orientations (B,K), box_feature (B,128,K),
+        input_point_cloud (B,N,3+f) -> object codes (B, c_dim, K)."""
+        xyz, features = self._break_up_pc(input_point_cloud)
+        # the instance-label channel is all zeros at generation time (:52-53)
+        features = torch.cat([features, torch.zeros_like(features)], dim=1)
+        xyz, features = self.stn(xyz, features, box_xyz, box_orientations)
+        B, _, K, P = features.size()
+        inp = torch.cat([xyz, features[:, 0].unsqueeze(1)], dim=1)          # (B, 3+f, K, P)
+        inp = inp.permute(0, 2, 3, 1).contiguous().view(B * K, P, -1)
+        seg_pred, _ = self.point_seg(inp.transpose(1, 2).contiguous())
+        mask = torch.argmax(seg_pred.view(B * K * P, 2), dim=1).view(B * K, P, 1)
+        box = box_feature.transpose(1, 2).contiguous().view(B * K, 1, -1).expand(-1, P, -1)
+        enc_in = torch.cat([inp, box], dim=2) * mask.float()
+        codes = self.encoder(enc_in)
+        return codes.view(B, K, -1).transpose(1, 2)

@@ -1,0 +1,184 @@
+"""Set-abstraction / feature-propagation / STN modules with the reference's
+class names, constructor keywords and state_dict keys
+(external/pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py):
+
+  build_shared_mlp          :9-19    Conv2d(1x1, bias=not bn) [+ BatchNorm2d] + ReLU
+                                     -> keys mlp_module.{0,1,3,4,6,7}.*
+  PointnetSAModuleVotes     :149-260
+  PointnetFPModule          :345-405 -> keys mlp.{0,1,3,4}.*
+  STN3d / STN_Group         :420-537
+
+The point operators come from the HIP library; the shared MLPs are plain 1x1
+convolutions and stay on rocBLAS/MIOpen through torch.
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _ext, pointnet2_utils
+
+
+def build_shared_mlp(mlp_spec: List[int], bn: bool = True):
+    layers = []
+    for c_in, c_out in zip(mlp_spec[:-1], mlp_spec[1:]):
+        layers.append(nn.Conv2d(c_in, c_out, kernel_size=1, bias=not bn))
+        if bn:
+            layers.append(nn.BatchNorm2d(c_out))
+        layers.append(nn.ReLU(True))
+    return nn.Sequential(*layers)
+
+
+class PointnetSAModuleVotes(nn.Module):
+    """Set abstraction with returned sample indices (VoteNet variant)."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None,
+                 nsample: int = None, bn: bool = True, use_xyz: bool = True,
+                 pooling: str = 'max', sigma: float = None, normalize_xyz: bool = False,
+                 sample_uniformly: bool = False, ret_unique_cnt: bool = False):
+        super().__init__()
+        if pooling not in ('max', 'avg', 'rbf'):
+            raise ValueError("unknown pooling %r" % pooling)
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.pooling = pooling
+        self.use_xyz = use_xyz
+        self.sigma = sigma if sigma is not None else (radius / 2 if radius is not None else None)
+        self.normalize_xyz = normalize_xyz
+        self.ret_unique_cnt = ret_unique_cnt
+        if npoint is not None:
+            self.grouper = pointnet2_utils.QueryAndGroup(
+                radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
+                normalize_xyz=normalize_xyz, sample_uniformly=sample_uniformly,
+                ret_unique_cnt=ret_unique_cnt)
+        else:
+            self.grouper = pointnet2_utils.GroupAll(use_xyz, ret_grouped_xyz=True)
+        spec = list(mlp)
+        if use_xyz and len(spec) > 0:
+            spec[0] += 3                                  # xyz channels come first
+        self.mlp_module = build_shared_mlp(spec, bn=bn)
+
+    def forward(self, xyz, features=None, inds=None):
+        """xyz (B,N,3), features (B,C,N), optional inds (B,npoint) ->
+        (new_xyz (B,npoint,3), new_features (B,mlp[-1],npoint), inds)."""
+        new_xyz = None
+        if self.npoint is not None:
+            if inds is None:
+                # FPS kernel already holds the winner's coordinates: emit the
+                # centres with it instead of transpose + gather + transpose
+                inds, new_xyz = _ext.furthest_point_sampling_gather(xyz, self.npoint)
+            else:
+                assert inds.shape[1] == self.npoint
+                new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
+        new_features = self.mlp_module(grouped_features)          # (B, C', npoint, nsample)
+        if self.pooling == 'max':
+            new_features = new_features.max(dim=3)[0]
+        elif self.pooling == 'avg':
+            new_features = new_features.mean(dim=3)
+        else:  # 'rbf'
+            rbf = torch.exp(-1 * grouped_xyz.pow(2).sum(1) / (self.sigma ** 2) / 2)
+            new_features = torch.sum(new_features * rbf.unsqueeze(1), -1) / float(self.nsample)
+        return new_xyz, new_features, inds
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: inverse-distance interpolation from the 3 nearest
+    known points, skip concatenation, shared MLP."""
+
+    def __init__(self, mlp, bn=True):
+        super().__init__()
+        self.mlp = build_shared_mlp(mlp, bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
+        if unknow_feats is not None:
+            new_features = torch.cat([interpolated, unknow_feats], dim=1)
+        else:
+            new_features = interpolated
+        return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
+
+
+def weights_init(m):
+    """STN layers start from the identity transform (all-zero weights)."""
+    if isinstance(m, (nn.Conv2d, nn.Linear)) or m.__class__.__name__.find('Conv2d') != -1:
+        if getattr(m, 'weight', None) is not None:
+            nn.init.constant_(m.weight.data, 0.0)
+        if getattr(m, 'bias', None) is not None:
+            nn.init.constant_(m.bias.data, 0.0)
+
+
+class STN3d(nn.Module):
+    """Per-proposal 3x4 affine regressor (PointNet T-net style)."""
+
+    def __init__(self, num_points=2500):
+        super().__init__()
+        self.num_points = num_points
+        self.conv1 = nn.Conv1d(3, 64, 1)
+        self.conv2 = nn.Conv1d(64, 128, 1)
+        self.conv3 = nn.Conv1d(128, 256, 1)
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.fc1 = nn.Linear(256, 128)
+        self.fc2 = nn.Linear(128, 64)
+        self.fc3 = nn.Linear(64, 12)
+        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = nn.BatchNorm1d(64)
+        self.bn2 = nn.BatchNorm1d(128)
+        self.bn3 = nn.BatchNorm1d(256)
+        self.bn4 = nn.BatchNorm1d(128)
+        self.bn5 = nn.BatchNorm1d(64)
+        self.apply(weights_init)
+
+    def forward(self, grouped_xyz):
+        B, _, P, _ = grouped_xyz.size()
+        pts = grouped_xyz.transpose(2, 1).contiguous().view(B * P, 3, self.num_points)
+        x = self.relu(self.bn1(self.conv1(pts)))
+        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.relu(self.bn3(self.conv3(x)))
+        x = self.mp1(x).squeeze(2)
+        x = self.relu(self.bn4(self.fc1(x)))
+        x = self.relu(self.bn5(self.fc2(x)))
+        x = self.fc3(x)
+        iden = torch.eye(3, 4, device=x.device, dtype=x.dtype).view(1, 12)
+        x = (x + iden).view(B * P, 3, 4)
+        out = torch.bmm(x[:, :, :3], pts) + x[:, :, 3].unsqueeze(-1)
+        return out.view(B, P, 3, -1).transpose(1, 2)
+
+
+class STN_Group(nn.Module):
+    """Group scan points around box centres, rotate them into the box frame
+    (-heading about z) and apply the learned STN3d affine."""
+
+    def __init__(self, radius: float = None, nsample: int = None, use_xyz: bool = True,
+                 normalize_xyz: bool = False, sample_uniformly: bool = False,
+                 ret_unique_cnt: bool = False):
+        super().__init__()
+        self.radius, self.nsample = radius, nsample
+        self.use_xyz = use_xyz
+        self.normalize_xyz = normalize_xyz
+        self.ret_unique_cnt = ret_unique_cnt
+        self.grouper = pointnet2_utils.QueryAndGroup(
+            radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True, normalize_xyz=normalize_xyz,
+            sample_uniformly=sample_uniformly, ret_unique_cnt=ret_unique_cnt)
+        self.stn3d = STN3d(num_points=nsample)
+
+    def forward(self, xyz, features=None, new_xyz=None, orientations=None):
+        grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
+        B, P = orientations.size()
+        cos, sin = torch.cos(orientations), torch.sin(orientations)
+        rot = torch.zeros(B, P, 3, 3, device=orientations.device, dtype=grouped_xyz.dtype)
+        rot[..., 0, 0] = cos
+        rot[..., 0, 1] = sin
+        rot[..., 1, 0] = -sin
+        rot[..., 1, 1] = cos
+        rot[..., 2, 2] = 1.
+        g = torch.bmm(rot.view(B * P, 3, 3),
+                      grouped_xyz.transpose(1, 2).contiguous().view(B * P, 3, -1))
+        g = g.view(B, P, 3, -1).transpose(1, 2).contiguous()
+        return self.stn3d(g), grouped_features

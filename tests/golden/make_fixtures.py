@@ -163,6 +163,126 @@ def make_grid():
     print("F_GRID ok")
 
 
+# ------------------------------------------------------------ network level ----
+def sub(a, step):
+    """strided subset of a flattened array (keeps fixtures small)"""
+    return np.ascontiguousarray(a.reshape(-1)[::step])
+
+
+def make_net():
+    """F-NET: the reference's Pointnet2Backbone / VotingModule / ProposalModule /
+    SkipPropagation run on CPU on top of the oracle `_ext`."""
+    import torch
+    mount_reference()
+    from rfdnet_amd.iscnet.config import Config
+    cfg = Config()
+    ns('models.registers')
+    reg = importlib.import_module('net_utils.registry')
+    sys.modules['models.registers'].MODULES = reg.Registry('module')
+    sys.modules['models.registers'].METHODS = reg.Registry('method')
+    sys.modules['models.registers'].LOSSES = reg.Registry('loss')
+    bbm = importlib.import_module('models.iscnet.modules.pointnet2backbone')
+    vm = importlib.import_module('models.iscnet.modules.vote_module')
+    pm = importlib.import_module('models.iscnet.modules.proposal_module')
+    sp = importlib.import_module('models.iscnet.modules.skip_propagation')
+    out = {}
+    pc = synthetic.synthetic_scene(seed=21, n_raw=6000, n_points=4096)
+    out['pc_seed'] = np.array([21, 6000, 4096])
+    x = torch.from_numpy(pc[None])
+    with torch.no_grad():
+        bb = bbm.Pointnet2Backbone(cfg)
+        names, shp = shapes_arrays(synthetic.load_seeded(bb, 101))
+        out['bb_names'], out['bb_shapes'] = names, shp
+        bb.eval()
+        ep = bb(x, {})
+        for k in ('sa1_inds', 'sa2_inds', 'fp2_inds'):
+            out['bb_' + k] = ep[k].numpy().astype(np.int32)
+        for k in ('sa1_xyz', 'sa2_xyz', 'sa3_xyz', 'sa4_xyz'):
+            out['bb_' + k] = ep[k].numpy()
+        for k, st in (('sa1_features', 37), ('sa2_features', 37), ('sa3_features', 17),
+                      ('sa4_features', 7), ('fp2_features', 37)):
+            out['bb_' + k] = sub(ep[k].numpy(), st)
+        vote = vm.VotingModule(cfg)
+        names, shp = shapes_arrays(synthetic.load_seeded(vote, 102))
+        out['vote_names'], out['vote_shapes'] = names, shp
+        vote.eval()
+        vxyz, vfeat = vote(ep['fp2_xyz'], ep['fp2_features'])
+        vfeat = vfeat.div(torch.norm(vfeat, p=2, dim=1).unsqueeze(1))      # demo.py:215-216
+        out['vote_xyz'] = vxyz.numpy()
+        out['vote_features'] = sub(vfeat.numpy(), 37)
+        prop = pm.ProposalModule(cfg)
+        names, shp = shapes_arrays(synthetic.load_seeded(prop, 103))
+        out['prop_names'], out['prop_shapes'] = names, shp
+        prop.eval()
+        ep['seed_xyz'] = ep['fp2_xyz']
+        ep, pf = prop(vxyz, vfeat, ep, True)
+        for k in ('aggregated_vote_inds',):
+            out['prop_' + k] = ep[k].numpy().astype(np.int32)
+        for k in ('aggregated_vote_xyz', 'center', 'objectness_scores', 'heading_scores',
+                  'heading_residuals_normalized', 'size_scores', 'size_residuals_normalized',
+                  'sem_cls_scores'):
+            out['prop_' + k] = ep[k].numpy()
+        out['prop_features'] = sub(pf.numpy(), 7)
+        # skip propagation on 6 of the proposals
+        skip = sp.SkipPropagation(cfg)
+        names, shp = shapes_arrays(synthetic.load_seeded(skip, 104))
+        out['skip_names'], out['skip_shapes'] = names, shp
+        skip.eval()
+        ids = torch.tensor([[3, 50, 97, 130, 200, 255]])
+        centers = torch.gather(ep['center'], 1, ids.unsqueeze(-1).expand(-1, -1, 3))
+        feats = torch.gather(pf, 2, ids.unsqueeze(1).expand(-1, 128, -1))
+        hc = torch.argmax(ep['heading_scores'], -1)
+        res = ep['heading_residuals_normalized'] * (np.pi / 12)
+        hr = torch.gather(res, 2, hc.unsqueeze(-1)).squeeze(2)
+        ang = cfg.dataset_config.class2angle_cuda(hc, hr)
+        ang = torch.gather(ang, 1, ids)
+        codes = skip.generate(centers, ang, feats, x)
+        out['skip_ids'] = ids.numpy()
+        out['skip_angles'] = ang.numpy()
+        out['skip_codes'] = codes.numpy()
+    np.savez_compressed(os.path.join(HERE, "F_NET.npz"), **out)
+    print("F_NET ok", {k: v.shape for k, v in out.items() if not k.endswith(('names', 'shapes'))})
+
+
+def make_gen():
+    """F-GEN: reference ONet + Generator3D (dense 16^3 and MISE 16 -> 32) with the
+    MISE built from the reference's mise.pyx; value grids captured at extract_mesh."""
+    import torch
+    mount_reference()
+    mise = build_ref_mise()
+    ns('external.libmise').MISE = mise.MISE
+    ns('models.registers')
+    reg = importlib.import_module('net_utils.registry')
+    sys.modules['models.registers'].MODULES = reg.Registry('module')
+    sys.modules['models.registers'].METHODS = reg.Registry('method')
+    sys.modules['models.registers'].LOSSES = reg.Registry('loss')
+    from rfdnet_amd.iscnet.config import Config
+    onet_mod = importlib.import_module('models.iscnet.modules.occupancy_net')
+    gen_mod = importlib.import_module('models.iscnet.modules.generator')
+    out = {}
+    rng = np.random.default_rng(5)
+    codes = rng.normal(0, 1, (3, 512)).astype(np.float32)
+    out['codes'] = codes
+    for tag, steps in (('dense16', 0), ('mise16x1', 1), ('mise8x2', 2)):
+        res0 = 8 if tag == 'mise8x2' else 16
+        cfg = Config({'generation': {'resolution_0': res0, 'upsampling_steps': steps}})
+        onet = onet_mod.ONet(cfg)
+        shapes = synthetic.load_seeded(onet, 202)
+        if tag == 'dense16':
+            names, shp = shapes_arrays(shapes)
+            out['onet_names'], out['onet_shapes'] = names, shp
+        onet.eval()
+        grids = []
+        gen_mod.Generator3D.extract_mesh = lambda self, occ_hat, z, c=None: grids.append(np.array(occ_hat)) or None
+        with torch.no_grad():
+            onet.generator.generate_mesh(torch.from_numpy(codes), None)
+        g = np.stack(grids)
+        out[tag + '_grid'] = g.astype(np.float32)
+        assert np.array_equal(g.astype(np.float32).astype(g.dtype), g)
+        print("F_GEN", tag, g.shape, float(g.min()), float(g.max()), (g > 0).mean())
+    np.savez_compressed(os.path.join(HERE, "F_GEN.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["dec", "mise", "grid"]
     for w in what:

@@ -1,0 +1,262 @@
+"""GPU (-m gpu): batched MISE state machine, dense grids, generator and marching
+cubes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rfdnet_amd import synthetic
+from rfdnet_amd.iscnet.config import Config
+
+pytestmark = pytest.mark.gpu
+TILE = 128
+
+
+def gpu_mise(hip, fields, res0, depth, thr):
+    """Drive csrc/mise.hip exactly as the generator does, but with analytic
+    fields evaluated on the host (so the oracle sees identical values)."""
+    lib = hip.lib()
+    K = len(fields)
+    R1 = (res0 << depth) + 1
+    n_per = R1 ** 3
+    dev = torch.device("cuda")
+    values = torch.zeros(K, n_per, device=dev)
+    pstate = torch.empty(K, n_per, dtype=torch.uint8, device=dev)
+    vstate = torch.empty(K, lib.rfd_mise_vstate_elems(res0, depth), dtype=torch.uint8, device=dev)
+    counts = torch.empty(K, dtype=torch.int32, device=dev)
+    st = hip.current_stream()
+    hip.check(lib.rfd_mise_init(K, res0, depth, pstate.data_ptr(), vstate.data_ptr(), st), "init")
+    per_round = []
+    for _ in range(64):
+        hip.check(lib.rfd_mise_count(K, res0, depth, pstate.data_ptr(), counts.data_ptr(), st), "count")
+        cnt = counts.cpu().numpy().astype(np.int64)
+        if cnt.sum() == 0:
+            break
+        per_round.append(cnt.copy())
+        tiles = (cnt + TILE - 1) // TILE
+        offs = (np.concatenate([[0], np.cumsum(tiles)[:-1]]) * TILE).astype(np.int32)
+        n_tiles = int(tiles.sum())
+        tile_prop = torch.from_numpy(np.repeat(np.arange(K, dtype=np.int32), tiles)).cuda()
+        pts = torch.zeros(n_tiles * TILE, 3, device=dev)
+        lin = torch.full((n_tiles * TILE,), -1, dtype=torch.int32, device=dev)
+        cursors = torch.zeros(K, dtype=torch.int32, device=dev)
+        hip.check(lib.rfd_mise_collect(K, res0, depth, pstate.data_ptr(), torch.from_numpy(offs).cuda().data_ptr(),
+                                       cursors.data_ptr(), 1.1, pts.data_ptr(), lin.data_ptr(), st), "collect")
+        l = lin.cpu().numpy()
+        p = pts.cpu().numpy()
+        tp = np.repeat(tile_prop.cpu().numpy(), TILE)
+        coords = np.stack([l // (R1 * R1), (l // R1) % R1, l % R1], 1)
+        # the float query points follow generator.py:106-109
+        ok = l >= 0
+        expect = (np.float32(1.1) * (coords[ok].astype(np.float32) / np.float32(R1 - 1) - np.float32(0.5)))
+        np.testing.assert_array_equal(p[ok], expect.astype(np.float32))
+        logits = np.zeros(l.shape[0], dtype=np.float32)
+        for k in range(K):
+            m = ok & (tp == k)
+            assert m.sum() == cnt[k]
+            logits[m] = fields[k](coords[m], R1 - 1).astype(np.float32)
+        hip.check(lib.rfd_mise_scatter(n_tiles, res0, depth, tile_prop.data_ptr(), lin.data_ptr(),
+                                       torch.from_numpy(logits).cuda().data_ptr(), values.data_ptr(),
+                                       pstate.data_ptr(), st), "scatter")
+        hip.check(lib.rfd_mise_subdivide(K, res0, depth, float(thr), values.data_ptr(), pstate.data_ptr(),
+                                         vstate.data_ptr(), st), "subdivide")
+    hip.check(lib.rfd_mise_to_dense(K, res0, depth, values.data_ptr(), pstate.data_ptr(), st), "dense")
+    return values.view(K, R1, R1, R1).cpu().numpy(), per_round
+
+
+def oracle_mise(oracle, field, res0, depth, thr):
+    m = oracle.MISE(res0, depth, thr)
+    counts = []
+    p = m.query()
+    while p.shape[0]:
+        counts.append(p.shape[0])
+        m.update(p, field(p, m.resolution).astype(np.float32).astype(np.float64))
+        p = m.query()
+    return m.to_dense(), counts
+
+
+def sphere(r, c=(0.5, 0.5, 0.5)):
+    return lambda p, R: r - np.sqrt(((p.astype(np.float64) / R - np.array(c)) ** 2).sum(-1))
+
+
+def two_blobs(p, R):
+    q = p.astype(np.float64) / R
+    return np.maximum(0.18 - np.linalg.norm(q - [0.3, 0.3, 0.35], axis=-1),
+                      0.12 - np.linalg.norm(q - [0.72, 0.66, 0.6], axis=-1))
+
+
+def thin_slab(p, R):      # sheet thinner than a coarse voxel: only found through neighbours' splits
+    q = p.astype(np.float64) / R
+    return 0.02 - np.abs(q[:, 0] - 0.53) - 0.3 * np.abs(q[:, 1] - 0.5)
+
+
+def plane_on_threshold(p, R):   # exact zeros: exercises the non-strict >= / <= (mise.pyx:225-227)
+    return (p[:, 0] - R // 2).astype(np.float64)
+
+
+@pytest.mark.parametrize("res0,depth", [(4, 1), (8, 2), (16, 1), (4, 3), (32, 1)])
+def test_batched_mise_equals_octree_oracle(hip, oracle, res0, depth):
+    fields = [sphere(0.35), two_blobs, thin_slab, plane_on_threshold,
+              lambda p, R: -np.ones(p.shape[0]), sphere(0.2, (0.4, 0.55, 0.6))]
+    dense, rounds = gpu_mise(hip, fields, res0, depth, 0.0)
+    for k, f in enumerate(fields):
+        ref, counts = oracle_mise(oracle, f, res0, depth, 0.0)
+        np.testing.assert_array_equal(dense[k].astype(np.float64), ref)
+        assert [int(r[k]) for r in rounds if r[k] > 0] == counts       # same per-round query counts
+
+
+def test_batched_mise_nonzero_threshold(hip, oracle):
+    thr = float(np.log(0.2) - np.log(0.8))
+    fields = [lambda p, R: 3 * sphere(0.3)(p, R) - 1.0, two_blobs]
+    dense, _ = gpu_mise(hip, fields, 8, 2, thr)
+    for k, f in enumerate(fields):
+        ref, _ = oracle_mise(oracle, f, 8, 2, thr)
+        np.testing.assert_array_equal(dense[k].astype(np.float64), ref)
+
+
+def test_dense_grid_points_match_oracle(hip, oracle):
+    lib = hip.lib()
+    for n in (2, 3, 8, 32, 33):
+        npad = (n ** 3 + TILE - 1) // TILE * TILE
+        pts = torch.empty(npad, 3, device="cuda")
+        hip.check(lib.rfd_make_grid_points(n, -0.5, 0.5, 1.1, pts.data_ptr(), npad, hip.current_stream()), "grid")
+        np.testing.assert_array_equal(pts.cpu().numpy()[: n ** 3], oracle.make_3d_grid(-0.5, 0.5, n, 1.1))
+        assert float(pts[n ** 3:].abs().sum()) == 0.0
+
+
+@pytest.fixture(scope="module")
+def onet_and_fixture(hip, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "F_GEN.npz"))
+    return fx
+
+
+def make_onet(res0, steps):
+    from rfdnet_amd.iscnet.occupancy_net import ONet
+    onet = ONet(Config({'generation': {'resolution_0': res0, 'upsampling_steps': steps}}))
+    # the reference ONet owns encoder_latent.* too: seed in the reference's key order
+    return onet
+
+
+def load_onet_seeded(onet, fx, seed=202):
+    from collections import OrderedDict
+    shapes = OrderedDict((str(n), tuple(int(x) for x in str(s).split(",")) if str(s) else ())
+                         for n, s in zip(fx["onet_names"], fx["onet_shapes"]))
+    sd = synthetic.seeded_state_dict(shapes, seed)
+    own = onet.state_dict()
+    onet.load_state_dict({k: torch.from_numpy(sd[k]) for k in own})
+    return onet.cuda().eval()
+
+
+def test_generator_dense_grid_matches_reference(hip, onet_and_fixture):
+    fx = onet_and_fixture
+    onet = load_onet_seeded(make_onet(16, 0), fx)
+    grids = onet.generator.generate_grids(torch.from_numpy(fx["codes"]).cuda(), None)
+    hip.device_status()
+    assert grids.shape == (3, 16, 16, 16)
+    assert np.abs(grids.cpu().numpy() - fx["dense16_grid"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("tag,res0,steps", [("mise16x1", 16, 1), ("mise8x2", 8, 2)])
+def test_generator_mise_grid_matches_reference(hip, onet_and_fixture, tag, res0, steps):
+    """Reference Generator3D + compiled mise.pyx vs the batched device pipeline.
+    MISE is data dependent: a logit within 1e-6 of the threshold may flip a
+    subdivision, so a vanishing fraction of fine points may be filled instead of
+    evaluated -- everything else must agree to the logit tolerance."""
+    fx = onet_and_fixture
+    onet = load_onet_seeded(make_onet(res0, steps), fx)
+    grids = onet.generator.generate_grids(torch.from_numpy(fx["codes"]).cuda(), None).cpu().numpy()
+    hip.device_status()
+    ref = fx[tag + "_grid"]
+    assert grids.shape == ref.shape
+    bad = np.abs(grids - ref) > 1e-4
+    assert bad.mean() < 1e-3, bad.mean()
+    assert ((grids > 0) == (ref > 0)).mean() > 0.9999
+
+
+# ------------------------------------------------------------ marching cubes ----
+def np_marching_cubes_soup(grid, iso, pad=-1e6):
+    """independent numpy restatement: triangle soup from the derived table"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_mc_tables as G
+    table = G.build()
+    g = np.pad(grid.astype(np.float64), 1, constant_values=pad)
+    D = g.shape[0]
+    tris = []
+    C = G.CORNERS.astype(int)
+    for i in range(D - 1):
+        for j in range(D - 1):
+            for k in range(D - 1):
+                v = [g[i + c[0], j + c[1], k + c[2]] for c in C]
+                ci = sum(1 << c for c in range(8) if v[c] < iso)
+                for t in table[ci]:
+                    P = []
+                    for e in t:
+                        a, b = G.EDGES[e]
+                        lo, hi = (a, b) if tuple(C[a]) <= tuple(C[b]) else (b, a)
+                        f1, f2 = v[lo], v[hi]
+                        mu = 0.5 if f1 == f2 else (iso - f1) / (f2 - f1)
+                        P.append(np.array([i, j, k]) + C[lo] + mu * (C[hi] - C[lo]))
+                    tris.append(P)
+    return np.array(tris).reshape(-1, 3, 3)
+
+
+def canon(tri_xyz):
+    """orientation-preserving canonical form: rotate each triangle so its
+    lexicographically smallest vertex comes first, then sort the triangles"""
+    t = np.round(tri_xyz, 9)
+    out = []
+    for tri in t:
+        keys = [tuple(p) for p in tri]
+        s = keys.index(min(keys))
+        out.append(keys[s] + keys[(s + 1) % 3] + keys[(s + 2) % 3])
+    return sorted(out)
+
+
+def field_grid(n, fn):
+    g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    return fn(g, n - 1).reshape(n, n, n).astype(np.float32)
+
+
+def test_marching_cubes_matches_numpy_restatement_and_is_watertight(hip):
+    from rfdnet_amd.iscnet.mcubes import marching_cubes_batch
+    n = 12
+    rng = np.random.default_rng(0)
+    grids = np.stack([field_grid(n, sphere(0.33)), field_grid(n, two_blobs),
+                      rng.normal(size=(n, n, n)).astype(np.float32),         # every case incl. ambiguous
+                      np.full((n, n, n), -1, dtype=np.float32),              # empty
+                      np.full((n, n, n), 1, dtype=np.float32)])              # solid: closed by the padding
+    out = marching_cubes_batch(torch.from_numpy(grids).cuda(), 0.0)
+    for k in range(grids.shape[0]):
+        v, f = out[k][0].cpu().numpy(), out[k][1].cpu().numpy()
+        ref = np_marching_cubes_soup(grids[k], 0.0)
+        assert f.shape[0] == ref.shape[0]
+        if f.shape[0] == 0:
+            continue
+        assert canon(v[f]) == canon(ref)
+        # shared vertices: every vertex is used, no duplicates
+        assert len(np.unique(f)) == v.shape[0] and len(np.unique(np.round(v, 9), axis=0)) == v.shape[0]
+        # closed, consistently oriented 2-manifold: each directed edge once, its reverse once
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        de = set(map(tuple, e))
+        assert len(de) == e.shape[0]
+        assert all((b, a) in de for a, b in de)
+    # outward normals: positive signed volume for the solid sphere, ~ (4/3) pi r^3
+    v, f = out[0][0].cpu().numpy(), out[0][1].cpu().numpy()
+    vol = np.einsum('ij,ij->i', v[f[:, 0]], np.cross(v[f[:, 1]], v[f[:, 2]])).sum() / 6
+    r = 0.33 * (n - 1)
+    assert 0.85 * 4 / 3 * np.pi * r ** 3 < vol < 1.05 * 4 / 3 * np.pi * r ** 3
+
+
+def test_generate_mesh_end_to_end_scaling(hip, onet_and_fixture):
+    """vertices land in the padded unit box of generator.py:163-168"""
+    fx = onet_and_fixture
+    onet = load_onet_seeded(make_onet(16, 1), fx)
+    meshes = onet.generator.generate_mesh(torch.from_numpy(fx["codes"]).cuda(), None)
+    assert len(meshes) == 3
+    for m in meshes:
+        v = m.vertices.cpu().numpy()
+        assert v.shape[0] > 0 and m.faces.shape[1] == 3
+        assert v.min() >= -0.55 * (1 + 1 / 32) - 1e-9 and v.max() <= 0.55 * (1 + 1 / 32) + 1e-9
+        assert int(m.faces.max()) < v.shape[0]

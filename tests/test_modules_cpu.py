@@ -1,0 +1,102 @@
+"""CPU: host-side mirror of the reference interface -- registry names,
+constructor signatures and state_dict keys/shapes (pinned by the name/shape
+lists captured from the reference's own classes in F_NET / F_GEN / F_DEC)."""
+import os
+
+import numpy as np
+import pytest
+
+from rfdnet_amd.iscnet.config import Config
+
+
+def ref_keys(fx, prefix):
+    return [(str(n), tuple(int(x) for x in str(s).split(",")) if str(s) else ())
+            for n, s in zip(fx[prefix + "_names"], fx[prefix + "_shapes"])]
+
+
+def my_keys(m):
+    return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+
+
+@pytest.fixture(scope="module")
+def fnet(golden_dir):
+    return np.load(os.path.join(golden_dir, "F_NET.npz"))
+
+
+def test_registry_has_the_reference_names():
+    from rfdnet_amd.iscnet import network  # noqa: F401
+    from rfdnet_amd.iscnet.registers import METHODS, MODULES
+    assert sorted(MODULES.module_dict) == ['ONet', 'Pointnet2Backbone', 'ProposalModule',
+                                           'SkipPropagation', 'VotingModule']
+    assert list(METHODS.module_dict) == ['ISCNet']
+    assert MODULES.get('nope', 'ONet') is MODULES.get('ONet')       # alter_key behaviour, registry.py:27-31
+    with pytest.raises(KeyError):
+        MODULES.register_module(MODULES.get('ONet'))
+
+
+def test_backbone_keys(fnet):
+    from rfdnet_amd.iscnet.pointnet2backbone import Pointnet2Backbone
+    assert my_keys(Pointnet2Backbone(Config())) == ref_keys(fnet, "bb")
+
+
+def test_voting_keys(fnet):
+    from rfdnet_amd.iscnet.vote_module import VotingModule
+    assert my_keys(VotingModule(Config())) == ref_keys(fnet, "vote")
+
+
+def test_proposal_keys(fnet):
+    from rfdnet_amd.iscnet.proposal_module import ProposalModule
+    assert my_keys(ProposalModule(Config())) == ref_keys(fnet, "prop")
+
+
+def test_skip_propagation_keys(fnet):
+    from rfdnet_amd.iscnet.skip_propagation import SkipPropagation
+    assert my_keys(SkipPropagation(Config())) == ref_keys(fnet, "skip")
+
+
+def test_onet_decoder_keys_are_the_reference_subset(golden_dir):
+    """the reference ONet additionally owns encoder_latent.* (training-only, q(z|.));
+    everything else must match key for key"""
+    from rfdnet_amd.iscnet.occupancy_net import ONet
+    fx = np.load(os.path.join(golden_dir, "F_GEN.npz"))
+    ref = [kv for kv in ref_keys(fx, "onet") if not kv[0].startswith("encoder_latent.")]
+    assert my_keys(ONet(Config())) == ref
+
+
+def test_iscnet_assembles_by_phase_and_loads_reference_style_checkpoint():
+    import torch
+    from rfdnet_amd.iscnet.network import ISCNet
+    net = ISCNet(Config())
+    assert [n for n, _ in net.named_children()] == ['backbone', 'voting', 'detection',
+                                                    'skip_propagation', 'completion']
+    det = ISCNet(Config({'demo': {'phase': 'detection'}}))
+    assert [n for n, _ in det.named_children()] == ['backbone', 'voting', 'detection']
+    sd = {'module.' + k: torch.full_like(v, 2) for k, v in net.state_dict().items()
+          if k.startswith('voting.')}
+    sd['module.not_a_key'] = torch.zeros(1)
+    net.load_weight(sd)                                   # models/network.py:81-89 semantics
+    assert float(net.voting.conv1.weight.mean()) == 2.0
+
+
+def test_query_and_group_rejects_unbuilt_options():
+    from rfdnet_amd.pointnet2_ops.pointnet2_utils import QueryAndGroup
+    with pytest.raises(NotImplementedError):
+        QueryAndGroup(0.2, 16, sample_uniformly=True)
+
+
+def test_generator_logit_threshold_and_unbuilt_options():
+    from rfdnet_amd.iscnet.generator import Generator3D
+    g = Generator3D(None, threshold=0.5, resolution0=32, upsampling_steps=1)
+    assert g.logit_threshold() == 0.0                      # generator.py:85
+    assert abs(Generator3D(None, threshold=0.2).logit_threshold() - np.log(0.25)) < 1e-12
+    with pytest.raises(NotImplementedError):
+        Generator3D(None, refinement_step=3)
+
+
+def test_synthetic_scene_is_reproducible_and_has_the_awkward_points():
+    from rfdnet_amd import synthetic
+    a = synthetic.synthetic_scene(seed=10, n_raw=30000, n_points=40000)
+    b = synthetic.synthetic_scene(seed=10, n_raw=30000, n_points=40000)
+    assert np.array_equal(a, b) and a.shape == (40000, 4) and a.dtype == np.float32
+    assert len(np.unique(a, axis=0)) < 40000               # sampled with replacement => duplicates
+    assert ((a[:, :3] ** 2).sum(1) <= 1e-3).sum() >= 1     # near-origin points (FPS skip rule)
