@@ -103,7 +103,8 @@ int three_interpolate_grad_kernel_wrapper(int b, int c, int n, int m,
 /* ---- fused forms (no reference counterpart; used by the host mirror of
  * QueryAndGroup, pointnet2_utils.py:302-361, to avoid materialising and
  * re-reading the grouped tensor).  Results are bit-identical to composing the
- * reference ops: group(xyz^T, idx) - centre [ / radius ] and group(features). */
+ * reference ops ON A GPU: group(xyz^T, idx) - centre [ * (1.0f / radius), which
+ * is how torch divides a device tensor by a Python scalar ] and group(features). */
 
 /* out (b, 3+c, m, nsample): channels 0..2 = (xyz[idx] - new_xyz) [/ radius if
  * normalize], channels 3.. = features[:, idx].  features may be NULL (c = 0).

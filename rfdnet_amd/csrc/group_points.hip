@@ -53,7 +53,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
 //   out[:, 3: ]  = features[:, idx]
 // blockIdx.y == 0 handles the xyz channels, y >= 1 the feature chunks.
 __global__ __launch_bounds__(GP_THREADS) void group_concat_kernel(
-    int c, int n, int m, int ns, float radius, int normalize, int use_xyz,
+    int c, int n, int m, int ns, float inv_radius, int normalize, int use_xyz,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ features, const int *__restrict__ idx,
     float *__restrict__ out, float *__restrict__ gxyz_out) {
@@ -71,8 +71,11 @@ __global__ __launch_bounds__(GP_THREADS) void group_concat_kernel(
     float g[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      g[a] = q[a] - ctr[a];                 // grouped_xyz -= new_xyz (:335)
-      if (normalize) g[a] = g[a] / radius;  // grouped_xyz /= radius  (:337)
+      g[a] = q[a] - ctr[a];                    // grouped_xyz -= new_xyz (:335)
+      // grouped_xyz /= radius (:337).  On a GPU tensor torch divides by a
+      // Python scalar as x * (1.0f / radius) (ATen div kernel, CPU-scalar
+      // fast path) -- that is what the reference executes, so do the same.
+      if (normalize) g[a] = g[a] * inv_radius;
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -134,7 +137,7 @@ RFD_API int rfd_group_concat(int b, int c, int n, int m, int nsample,
   hipLaunchKernelGGL(group_concat_kernel,
                      dim3(ceil_div(mn, GP_THREADS), 1 + ceil_div(c, GP_CH), b),
                      dim3(GP_THREADS), 0, (hipStream_t)stream, c, n, m, nsample,
-                     radius, normalize, use_xyz, xyz, new_xyz, features, idx,
+                     1.0f / radius, normalize, use_xyz, xyz, new_xyz, features, idx,
                      out, grouped_xyz_out);
   RFD_CHECK_LAUNCH();
   return 0;

@@ -1,6 +1,7 @@
 """GPU (-m gpu): batched MISE state machine, dense grids, generator and marching
 cubes."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -9,6 +10,7 @@ import torch
 from rfdnet_amd import synthetic
 from rfdnet_amd.iscnet.config import Config
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 TILE = 128
 
@@ -175,43 +177,7 @@ def test_generator_mise_grid_matches_reference(hip, onet_and_fixture, tag, res0,
 
 
 # ------------------------------------------------------------ marching cubes ----
-def np_marching_cubes_soup(grid, iso, pad=-1e6):
-    """independent numpy restatement: triangle soup from the derived table"""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import gen_mc_tables as G
-    table = G.build()
-    g = np.pad(grid.astype(np.float64), 1, constant_values=pad)
-    D = g.shape[0]
-    tris = []
-    C = G.CORNERS.astype(int)
-    for i in range(D - 1):
-        for j in range(D - 1):
-            for k in range(D - 1):
-                v = [g[i + c[0], j + c[1], k + c[2]] for c in C]
-                ci = sum(1 << c for c in range(8) if v[c] < iso)
-                for t in table[ci]:
-                    P = []
-                    for e in t:
-                        a, b = G.EDGES[e]
-                        lo, hi = (a, b) if tuple(C[a]) <= tuple(C[b]) else (b, a)
-                        f1, f2 = v[lo], v[hi]
-                        mu = 0.5 if f1 == f2 else (iso - f1) / (f2 - f1)
-                        P.append(np.array([i, j, k]) + C[lo] + mu * (C[hi] - C[lo]))
-                    tris.append(P)
-    return np.array(tris).reshape(-1, 3, 3)
-
-
-def canon(tri_xyz):
-    """orientation-preserving canonical form: rotate each triangle so its
-    lexicographically smallest vertex comes first, then sort the triangles"""
-    t = np.round(tri_xyz, 9)
-    out = []
-    for tri in t:
-        keys = [tuple(p) for p in tri]
-        s = keys.index(min(keys))
-        out.append(keys[s] + keys[(s + 1) % 3] + keys[(s + 2) % 3])
-    return sorted(out)
+from mc_ref import canon, marching_cubes_soup as np_marching_cubes_soup  # noqa: E402
 
 
 def field_grid(n, fn):

@@ -208,7 +208,7 @@ def test_group_concat_equals_reference_composition(ext, oracle):
     idx = oracle.ball_query(new, xyz, r, ns)
     gx = oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx)
     gx = gx - new.transpose(0, 2, 1)[..., None]
-    gxn = (gx / np.float32(r)).astype(np.float32)
+    gxn = (gx * (np.float32(1.0) / np.float32(r))).astype(np.float32)   # torch GPU: x * (1/r)
     gf = oracle.group_points(feats, idx)
     out, g = ext.group_concat(dev(xyz), dev(new), dev(feats), dev(idx), r, True, True, True)
     np.testing.assert_array_equal(out.cpu().numpy(), np.concatenate([gxn, gf], 1))

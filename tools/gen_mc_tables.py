@@ -59,6 +59,50 @@ def face_segments(case, corners, normal):
     return segs
 
 
+def edges_share_face(e1, e2):
+    for corners, _ in FACES:
+        fe = {EDGE_ID[(corners[i], corners[(i + 1) % 4])] for i in range(4)}
+        if e1 in fe and e2 in fe:
+            return True
+    return False
+
+
+def polygon_triangulations(idx):
+    """all triangulations of the convex polygon with vertex list idx"""
+    if len(idx) < 3:
+        return [[]]
+    if len(idx) == 3:
+        return [[tuple(idx)]]
+    out = []
+    a, b = idx[0], idx[-1]
+    for m in range(1, len(idx) - 1):
+        for left in polygon_triangulations(idx[:m + 1]):
+            for right in polygon_triangulations(idx[m:]):
+                out.append(left + [(a, idx[m], b)] + right)
+    return out
+
+
+def best_triangulation(loop):
+    """Triangulate a loop of cube-edge vertices avoiding diagonals that lie in a
+    cube face (both end points on edges of one face, not adjacent in the loop):
+    such a diagonal can coincide with a diagonal of the neighbouring cell and
+    make the mesh non-manifold there.  Ties: prefer the plain fan."""
+    n = len(loop)
+    best, best_cost = None, None
+    for tri in polygon_triangulations(list(range(n))):
+        cost = 0
+        for t in tri:
+            for u, v in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+                if (u - v) % n in (1, n - 1):
+                    continue                      # polygon side, not a diagonal
+                if edges_share_face(loop[u], loop[v]):
+                    cost += 1
+        if best_cost is None or cost < best_cost:
+            best, best_cost = tri, cost
+    # keep the loop orientation: every triangle (i<j<k) in cyclic order
+    return [tuple(loop[i] for i in sorted(t)) for t in best], best_cost
+
+
 def triangulate(case):
     nxt = {}
     for corners, normal in FACES:
@@ -78,8 +122,9 @@ def triangulate(case):
             seen.add(cur)
             cur = nxt[cur]
         assert len(loop) >= 3
-        for i in range(1, len(loop) - 1):
-            tris.append((loop[0], loop[i], loop[i + 1]))
+        t, cost = best_triangulation(loop)
+        triangulate.max_cost = max(getattr(triangulate, "max_cost", 0), cost)
+        tris.extend(t)
     return tris
 
 
@@ -132,6 +177,7 @@ def main():
         for o in edge_owner():
             f.write("  {%d, %d, %d, %d},\n" % o)
         f.write("};\n")
+    print("in-face diagonals left (max per loop):", getattr(triangulate, "max_cost", 0))
     print("wrote", path, "max triangles per cell", maxt,
           "total triangles", sum(len(t) for t in table))
     return table
