@@ -70,40 +70,134 @@ __global__ void mise_init_voxels_kernel(size_t n0, size_t n_per,
   vstate[(size_t)blockIdx.y * n_per + e] = e < n0 ? 1 : 0;  // level 0: all leaves
 }
 
-__global__ void mise_count_kernel(size_t n_per, const unsigned char *__restrict__ pstate,
-                                  int *__restrict__ counts) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  int c = 0;
-  if (e < n_per) c = pstate[(size_t)k * n_per + e] == 1;
-  // wave-level reduction, one atomic per wave
-  const unsigned long long m = __ballot(c);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(counts + k, __popcll(m));
+// ---- 16 bytes of point state per thread ------------------------------------------
+// The state arrays are scanned as one flat byte stream of K*n_per bytes in
+// aligned 16-byte chunks (n_per = (R+1)^3 is odd, so a chunk may straddle two
+// proposals: `split` = number of its bytes that belong to the first one).
+struct Chunk {
+  unsigned w[4];   // the 16 state bytes (0 beyond the end of the array)
+  int k0;          // proposal of byte 0
+  int split;       // bytes [0,split) -> k0, [split,16) -> k0 + 1
+  size_t e0;       // lattice index (within k0) of byte 0
+};
+
+__device__ __forceinline__ Chunk load_chunk(const unsigned char *__restrict__ ps, size_t total,
+                                            size_t n_per, size_t chunk) {
+  Chunk c;
+  const size_t b0 = chunk * 16;
+  if (b0 + 16 <= total) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(ps + b0);
+    c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+  } else {
+    c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
+    for (int j = 0; j < 16; ++j)
+      if (b0 + j < total) c.w[j >> 2] |= (unsigned)ps[b0 + j] << (8 * (j & 3));
+  }
+  c.k0 = (int)(b0 / n_per);
+  c.e0 = b0 - (size_t)c.k0 * n_per;
+  const size_t left = n_per - c.e0;
+  c.split = left < 16 ? (int)left : 16;
+  return c;
 }
 
-__global__ void mise_collect_kernel(int R1, size_t n_per,
-                                    const unsigned char *__restrict__ pstate,
-                                    const int *__restrict__ offsets,
-                                    int *__restrict__ cursors, float box_size,
-                                    float *__restrict__ pts, int *__restrict__ lin) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  const bool want = e < n_per && pstate[(size_t)k * n_per + e] == 1;
-  const unsigned long long m = __ballot(want);
-  if (!m) return;
+// bit j set <=> state byte j == 1 (exists, unknown).  States are 0..3, so
+// (x | x>>1) & 1 tests "byte != 0" without cross-byte carries.
+__device__ __forceinline__ unsigned unknown_mask16(const Chunk &c) {
+  unsigned m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned x = c.w[q] ^ 0x01010101u;
+    const unsigned z = ~(x | (x >> 1)) & 0x01010101u;   // 1 where byte == 1
+    // gather the four flag bits (bits 0, 8, 16, 24) into a nibble
+    const unsigned nib = (z & 1u) | ((z >> 7) & 2u) | ((z >> 14) & 4u) | ((z >> 21) & 8u);
+    m |= nib << (4 * q);
+  }
+  return m;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void mise_count_kernel(size_t total, size_t n_per, int K,
+                                                         const unsigned char *__restrict__ pstate,
+                                                         int *__restrict__ counts) {
+  const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int c0 = 0, c1 = 0, k0 = -1;
+  if (chunk * 16 < total) {
+    const Chunk c = load_chunk(pstate, total, n_per, chunk);
+    const unsigned m = unknown_mask16(c);
+    const unsigned lo = c.split >= 16 ? 0xffffu : ((1u << c.split) - 1u);
+    c0 = __popc(m & lo);
+    c1 = __popc(m & ~lo);
+    k0 = c.k0;
+  }
+  const int kf = __shfl(k0, 0);
+  if (__all(k0 == kf && c1 == 0)) {          // common case: whole wave in one proposal
+    const int tot = wave_sum(c0);
+    if ((threadIdx.x & 63) == 0 && tot && kf >= 0) atomicAdd(counts + kf, tot);
+  } else {
+    if (c0) atomicAdd(counts + k0, c0);
+    if (c1 && k0 + 1 < K) atomicAdd(counts + k0 + 1, c1);
+  }
+}
+
+__global__ __launch_bounds__(256) void mise_collect_kernel(
+    int R1, size_t total, size_t n_per, int K, const unsigned char *__restrict__ pstate,
+    const int *__restrict__ offsets, int *__restrict__ cursors, float box_size,
+    float *__restrict__ pts, int *__restrict__ lin) {
+  const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(cursors + k, __popcll(m));
-  base = __shfl(base, 0);
-  if (!want) return;
-  const int slot = offsets[k] + base + __popcll(m & ((1ull << lane) - 1ull));
-  const int kz = (int)(e % R1), jy = (int)((e / R1) % R1), ix = (int)(e / ((size_t)R1 * R1));
+  unsigned m = 0, lo = 0xffffu;
+  int k0 = -1;
+  size_t e0 = 0;
+  if (chunk * 16 < total) {
+    const Chunk c = load_chunk(pstate, total, n_per, chunk);
+    m = unknown_mask16(c);
+    lo = c.split >= 16 ? 0xffffu : ((1u << c.split) - 1u);
+    k0 = c.k0;
+    e0 = c.e0;
+  }
+  const int c0 = __popc(m & lo), c1 = __popc(m & ~lo);
+  if (!__any(c0 | c1)) return;
+  int base0 = 0, base1 = 0;
+  const int kf = __shfl(k0, 0);
+  if (__all((k0 == kf || (c0 | c1) == 0) && c1 == 0)) {
+    // one atomic per wave + an in-wave exclusive prefix
+    int incl = c0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    const int tot = __shfl(incl, 63);
+    int wb = 0;
+    if (lane == 0) wb = atomicAdd(cursors + kf, tot);
+    wb = __shfl(wb, 0);
+    base0 = wb + incl - c0;
+  } else {                                   // a proposal boundary inside the wave
+    if (c0) base0 = atomicAdd(cursors + k0, c0);
+    if (c1 && k0 + 1 < K) base1 = atomicAdd(cursors + k0 + 1, c1);
+  }
   const float res = (float)(R1 - 1);
-  // pointsf = points / resolution; box_size * (pointsf - 0.5)  (generator.py:106-109)
-  pts[(size_t)slot * 3 + 0] = box_size * ((float)ix / res - 0.5f);
-  pts[(size_t)slot * 3 + 1] = box_size * ((float)jy / res - 0.5f);
-  pts[(size_t)slot * 3 + 2] = box_size * ((float)kz / res - 0.5f);
-  lin[slot] = (int)e;
+  unsigned mm = m;
+  while (mm) {
+    const int j = __ffs(mm) - 1;
+    mm &= mm - 1;
+    const bool second = !((lo >> j) & 1u);
+    const int k = second ? k0 + 1 : k0;
+    if (k >= K) break;
+    const size_t e = second ? (e0 + j - n_per) : (e0 + j);
+    const int slot = offsets[k] + (second ? base1++ : base0++);
+    const int kz = (int)(e % R1), jy = (int)((e / R1) % R1), ix = (int)(e / ((size_t)R1 * R1));
+    // pointsf = points / resolution; box_size * (pointsf - 0.5)  (generator.py:106-109)
+    pts[(size_t)slot * 3 + 0] = box_size * ((float)ix / res - 0.5f);
+    pts[(size_t)slot * 3 + 1] = box_size * ((float)jy / res - 0.5f);
+    pts[(size_t)slot * 3 + 2] = box_size * ((float)kz / res - 0.5f);
+    lin[slot] = (int)e;
+  }
 }
 
 __global__ void mise_scatter_kernel(size_t n_per, const int *__restrict__ tile_prop,
@@ -200,6 +294,40 @@ __global__ void mise_fill_kernel(int R1, int axis, size_t n_per, float *__restri
   }
 }
 
+// z-axis fill with a WAVE per line (lanes = k): coalesced, and the forward fill
+// is a ballot + "highest valid lane below me" shuffle instead of a serial scan.
+__global__ __launch_bounds__(256) void mise_fill_z_kernel(int R1, size_t n_per,
+                                                          float *__restrict__ values,
+                                                          unsigned char *__restrict__ pstate) {
+  const int lane = threadIdx.x & 63;
+  const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (line >= R1 * R1) return;                 // wave-uniform
+  const int kp = blockIdx.y;
+  float *vals = values + (size_t)kp * n_per + (size_t)line * R1;
+  unsigned char *ps = pstate + (size_t)kp * n_per + (size_t)line * R1;
+  float carry = 0.f;
+  bool carry_valid = false;
+  for (int k0 = 0; k0 < R1; k0 += 64) {        // R1 = 65, 129, ...: 2-3 segments
+    const int k = k0 + lane;
+    const bool in = k < R1;
+    const float v = in ? vals[k] : 0.f;
+    const bool valid = in && ps[k] >= 2;
+    const unsigned long long m = __ballot(valid);
+    const unsigned long long below = m & ((1ull << lane) - 1ull);
+    const int src = below ? 63 - __clzll((long long)below) : 0;
+    const float from = __shfl(v, src);
+    if (in && !valid) {
+      if (below) { vals[k] = from; ps[k] = 3; }
+      else if (carry_valid) { vals[k] = carry; ps[k] = 3; }
+    }
+    if (m) {                                   // last valid value of this segment
+      const int hi = 63 - __clzll((long long)m);
+      carry = __shfl(v, hi);
+      carry_valid = true;
+    }
+  }
+}
+
 }  // namespace
 
 RFD_API int rfd_make_grid_points(int n, float lo, float hi, float scale, float *pts,
@@ -239,8 +367,9 @@ RFD_API int rfd_mise_count(int K, int res0, int depth, const unsigned char *psta
   const size_t n_per = cube((size_t)R1);
   hipStream_t s = (hipStream_t)stream;
   RFD_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * K, s));
-  hipLaunchKernelGGL(mise_count_kernel, dim3((unsigned)((n_per + 255) / 256), K), dim3(256), 0, s,
-                     n_per, pstate, counts);
+  const size_t total = n_per * (size_t)K, chunks = (total + 15) / 16;
+  hipLaunchKernelGGL(mise_count_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s,
+                     total, n_per, K, pstate, counts);
   RFD_CHECK_LAUNCH();
   return 0;
 }
@@ -251,8 +380,10 @@ RFD_API int rfd_mise_collect(int K, int res0, int depth, const unsigned char *ps
   if (K <= 0) return 0;
   const int R1 = (res0 << depth) + 1;
   const size_t n_per = cube((size_t)R1);
-  hipLaunchKernelGGL(mise_collect_kernel, dim3((unsigned)((n_per + 255) / 256), K), dim3(256), 0,
-                     (hipStream_t)stream, R1, n_per, pstate, offsets, cursors, box_size, pts, lin);
+  const size_t total = n_per * (size_t)K, chunks = (total + 15) / 16;
+  hipLaunchKernelGGL(mise_collect_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, R1, total, n_per, K, pstate, offsets, cursors, box_size,
+                     pts, lin);
   RFD_CHECK_LAUNCH();
   return 0;
 }
@@ -292,10 +423,13 @@ RFD_API int rfd_mise_to_dense(int K, int res0, int depth, float *values,
   if (K <= 0) return 0;
   const int R1 = (res0 << depth) + 1;
   const size_t n_per = cube((size_t)R1);
-  for (int axis = 0; axis < 3; ++axis) {
+  for (int axis = 0; axis < 2; ++axis) {
     hipLaunchKernelGGL(mise_fill_kernel, dim3(ceil_div(R1 * R1, 256), K), dim3(256), 0,
                        (hipStream_t)stream, R1, axis, n_per, values, pstate);
     RFD_CHECK_LAUNCH();
   }
+  hipLaunchKernelGGL(mise_fill_z_kernel, dim3(ceil_div(R1 * R1, 4), K), dim3(256), 0,
+                     (hipStream_t)stream, R1, n_per, values, pstate);
+  RFD_CHECK_LAUNCH();
   return 0;
 }

@@ -97,41 +97,95 @@ __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// relu(s*x + t) of 16 accumulator values -> two B fragments (hi) and (lo).
-// Channel of register r: 8(r>>2) + 4*half + (r&3) within the 32-block, so the
-// table rows are read as four float4 per 16 registers.
-template <bool WITH_LO>
-__device__ __forceinline__ void cbn_relu_split(const f32x16 &x, const float *s_row,
-                                               const float *t_row, int ch0,
-                                               half8 &hi0, half8 &hi1, half8 &lo0,
-                                               half8 &lo1, float &amax) {
-  float v[16];
+// ---- activation epilogue, in slices -------------------------------------------
+// relu(s*x + t) of the 16 accumulator values of one 32-channel block, converted
+// to the next GEMM's B fragments.  Channel of register r: 8(r>>2) + 4*half +
+// (r&3), so the table rows are read as four float4.  The work is cut into 8
+// two-value SLICES so it can be issued in the shadow of another GEMM's MFMAs.
+struct EpiTab {
+  f32x4 s[4], t[4];
+};
+
+__device__ __forceinline__ EpiTab load_epi_tab(const float *s_row, const float *t_row, int ch0) {
+  EpiTab e;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_row + ch0 + 8 * q);
-    const f32x4 t4 = *reinterpret_cast<const f32x4 *>(t_row + ch0 + 8 * q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = __builtin_fmaf(s4[e], x[4 * q + e], t4[e]);
-      a = a > 0.f ? a : 0.f;
-      amax = a > amax ? a : amax;
-      v[4 * q + e] = a;
-    }
+    e.s[q] = *reinterpret_cast<const f32x4 *>(s_row + ch0 + 8 * q);
+    e.t[q] = *reinterpret_cast<const f32x4 *>(t_row + ch0 + 8 * q);
   }
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const float a0 = v[2 * p], a1 = v[2 * p + 1];
-    const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(a0, a1));
-    if (p < 4) { hi0[2 * p] = h2[0]; hi0[2 * p + 1] = h2[1]; }
-    else       { hi1[2 * (p - 4)] = h2[0]; hi1[2 * (p - 4) + 1] = h2[1]; }
-    if (WITH_LO) {
-      const float r0 = a0 - (float)h2[0], r1 = a1 - (float)h2[1];
-      const half2v l2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-      if (p < 4) { lo0[2 * p] = l2[0]; lo0[2 * p + 1] = l2[1]; }
-      else       { lo1[2 * (p - 4)] = l2[0]; lo1[2 * (p - 4) + 1] = l2[1]; }
-    }
+  return e;
+}
+
+// running max of packed non-negative f16 pairs, compared as u16 (monotone)
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <bool WITH_LO>
+__device__ __forceinline__ void epi_slice(int i, const f32x16 &x, const EpiTab &tb, unsigned (&hiw)[8],
+                                          unsigned (&low)[8], unsigned &amax16) {
+  const int q = i >> 1, e0 = 2 * (i & 1);
+  float a0 = __builtin_fmaf(tb.s[q][e0], x[2 * i], tb.t[q][e0]);
+  float a1 = __builtin_fmaf(tb.s[q][e0 + 1], x[2 * i + 1], tb.t[q][e0 + 1]);
+  a0 = a0 > 0.f ? a0 : 0.f;
+  a1 = a1 > 0.f ? a1 : 0.f;
+  const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(a0, a1));  // round to zero
+  hiw[i] = __builtin_bit_cast(unsigned, h2);
+  amax16 = pk_max_u16(amax16, hiw[i]);
+  if (WITH_LO) {
+    // a - (float)hi with one rounding; fma(ext(f16), -1, f32) maps to v_fma_mix_f32
+    const float r0 = __builtin_fmaf((float)h2[0], -1.0f, a0), r1 = __builtin_fmaf((float)h2[1], -1.0f, a1);
+    low[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+  } else {
+    low[i] = 0u;
   }
 }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half8 words_to_frag(const unsigned (&w)[8], int o) {
+  u32x4 v = {w[o], w[o + 1], w[o + 2], w[o + 3]};
+  return __builtin_bit_cast(half8, v);
+}
+
+// LDS carve-up (ONE static object: a second __shared__ object makes hipcc drain
+// vmcnt before every ds_read of an LDS-DMA pipeline; the base stays 16-B
+// aligned):  [ table 23x256 f32 | fc_p 256x3 f32 | fc_out 256 f32 | ring of
+// four 32-KiB half-chunks ]  = 27 648 + 131 072 = 158 720 B of the CU's 160 KiB.
+constexpr int SMEM_TAB_BYTES = (ROWS * H + H * 3 + H) * 4;
+constexpr int HALF_FRAGS = 32;                                // fragments per half-chunk
+constexpr int HALF_BYTES = HALF_FRAGS * FRAG_HALVES * 2;      // 32 KiB
+constexpr int N_HALVES = NB * 8 * 2;                          // 80
+constexpr int SMEM_BYTES = SMEM_TAB_BYTES + 4 * HALF_BYTES;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// One 1-KiB LDS-DMA piece (global_load_lds_dwordx4: lane-linear destination =
+// the fragment layout).  Half-chunk h = fragments [32h, 32h+32) of the stream:
+// even h = fc_0 fragments of chunk h/2, odd h = fc_1 fragments.  Wave w moves
+// fragments 8w..8w+7 of a half.
+__device__ __forceinline__ void dma_piece(const half8 *__restrict__ packed, unsigned char *s_slots,
+                                          int h, int j, int wave, int lane) {
+  const int frag = wave * 8 + j;
+  __builtin_amdgcn_global_load_lds(
+      (gbl_void *)(packed + ((size_t)h * HALF_FRAGS + frag) * 64 + lane),
+      (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, 0);
+}
+
+#ifdef RFD_DECODE_TRACE
+// debug build only (tools/dec_trace.py): wave 0 / lane 0 of the first tiles
+// overwrite their logits with s_memtime stamps of block 1's phases.
+#define TRACE_STAMP(slot)                                                              \
+  do {                                                                                 \
+    if (blk == 1 && wave == 0 && lane == 0 && tile < 64)                               \
+      reinterpret_cast<unsigned long long *>(logits)[(size_t)tile * 64 + (slot)] =     \
+          __builtin_amdgcn_s_memtime();                                                \
+  } while (0)
+#else
+#define TRACE_STAMP(slot) do { } while (0)
+#endif
 
 template <int TERMS>
 __global__ __launch_bounds__(256) void occ_decode_kernel(
@@ -140,16 +194,26 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
     const float *__restrict__ table, const float *__restrict__ fc_out_w,
     float fc_out_b, float *__restrict__ logits, unsigned *status) {
   constexpr bool X3 = TERMS == 3;
-  __shared__ __attribute__((aligned(16))) float s_tab[ROWS * H];  // 23 KB
-  __shared__ __attribute__((aligned(16))) float s_wp[H * 3];
-  __shared__ __attribute__((aligned(16))) float s_wo[H];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  float *s_tab = reinterpret_cast<float *>(smem);
+  float *s_wp = s_tab + ROWS * H;
+  float *s_wo = s_wp + H * 3;
+  unsigned char *s_slots = smem + SMEM_TAB_BYTES;
 
   const int tile = blockIdx.x;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int half = lane >> 5, n = lane & 31;
   const int prop = tile_prop[tile];
   if (prop < 0) return;  // padding tile (whole workgroup, before any barrier)
 
+  const size_t pidx = (size_t)tile * TILE + wave * 32 + n;
+  const size_t sidx = (size_t)(tile_src ? tile_src[tile] : tile) * TILE + wave * 32 + n;
+  const float px = pts[sidx * 3 + 0], py = pts[sidx * 3 + 1], pz = pts[sidx * 3 + 2];
+
+  // weights of chunk 0 (fc_0, fc_1) and chunk 1 (fc_0) in flight first
+#pragma unroll
+  for (int j = 0; j < 24; ++j) dma_piece(packed, s_slots, j >> 3, j & 7, wave, lane);
   {  // stage the per-proposal table + first/last layer weights
     const f32x4 *src = reinterpret_cast<const f32x4 *>(table + (size_t)prop * ROWS * H);
     f32x4 *dst = reinterpret_cast<f32x4 *>(s_tab);
@@ -157,11 +221,8 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
     for (int i = t; i < H * 3; i += 256) s_wp[i] = fc_p_w[i];
     if (t < H) s_wo[t] = fc_out_w[t];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-
-  const size_t pidx = (size_t)tile * TILE + wave * 32 + n;
-  const size_t sidx = (size_t)(tile_src ? tile_src[tile] : tile) * TILE + wave * 32 + n;
-  const float px = pts[sidx * 3 + 0], py = pts[sidx * 3 + 1], pz = pts[sidx * 3 + 2];
 
   // ---- fc_p (+ fc_z bias): H' = (Wp p + bp + zb) 2^KH, in accumulator layout
   f32x16 Hs[8];
@@ -178,55 +239,191 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
     }
   }
 
-  float amax = 0.f;
+  unsigned amax16 = 0u;
   half8 ahi[16], alo[16];  // B fragments of the block input, ks = 0..15
   for (int blk = 0; blk < NB; ++blk) {
     const float *S0 = s_tab + (1 + 4 * blk) * H, *T0 = S0 + H, *S1 = T0 + H, *T1 = S1 + H;
-    // a' = relu(S0' H' + T0') for all 256 channels
+    TRACE_STAMP(0);
+    // ---- a' = relu(S0' H' + T0') for all 256 channels, fused with fc_0 of the
+    // block's first 32 output channels: k-steps 2kb, 2kb+1 only need channel
+    // block kb, so block kb+1 is converted in the shadow of their six MFMAs.
+    f32x16 acc_cur = {0.f};
+    {
+      const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * blk * 8) & 3) * HALF_BYTES) + lane;
+      half8 fh = w[0], fl = w[X3 ? 64 : 0];
+      {
+        const EpiTab tb = load_epi_tab(S0, T0, 4 * half);
+        unsigned hw[8], lw[8];
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb)
-      cbn_relu_split<X3>(Hs[kb], S0, T0, 32 * kb + 4 * half, ahi[2 * kb], ahi[2 * kb + 1],
-                         alo[2 * kb], alo[2 * kb + 1], amax);
+        for (int i = 0; i < 8; ++i) epi_slice<X3>(i, Hs[0], tb, hw, lw, amax16);
+        ahi[0] = words_to_frag(hw, 0); ahi[1] = words_to_frag(hw, 4);
+        alo[0] = words_to_frag(lw, 0); alo[1] = words_to_frag(lw, 4);
+      }
+      TRACE_STAMP(1);
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        unsigned hw[8], lw[8];
+        EpiTab tb;
+        if (kb < 7) tb = load_epi_tab(S0, T0, 32 * (kb + 1) + 4 * half);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const int ks = 2 * kb + sub;
+          const half8 ch = fh, cl = fl;
+          if (ks < 15) {
+            fh = w[(2 * ks + 2) * 64];
+            if (X3) fl = w[(2 * ks + 3) * 64];
+          }
+          acc_cur = mfma(ch, ahi[ks], acc_cur);
+          if (X3) {
+            acc_cur = mfma(ch, alo[ks], acc_cur);
+            acc_cur = mfma(cl, ahi[ks], acc_cur);
+          }
+          if (kb < 7) {
+#pragma unroll
+            for (int i = 4 * sub; i < 4 * sub + 4; ++i) epi_slice<X3>(i, Hs[kb + 1], tb, hw, lw, amax16);
+          }
+          // issue order inside the step: each MFMA occupies the matrix pipe for
+          // 32 cycles and the next one (same accumulator) cannot start earlier,
+          // so independent LDS reads / VALU are slotted into those gaps
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          if (X3) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kb < 7) {
+          ahi[2 * kb + 2] = words_to_frag(hw, 0); ahi[2 * kb + 3] = words_to_frag(hw, 4);
+          alo[2 * kb + 2] = words_to_frag(lw, 0); alo[2 * kb + 3] = words_to_frag(lw, 4);
+        }
+      }
+    }
+    TRACE_STAMP(2);
+    // the slot just read is refilled by this iteration's LDS-DMA below
+    __syncthreads();
+
     for (int mb = 0; mb < 8; ++mb) {
-      const half8 *w = packed + ((size_t)(blk * 8 + mb) * FRAGS_PER_CHUNK) * 64 + lane;
-      // ---- GEMM1: 32 output channels of fc_0 over K = 256
-      f32x16 acc = {0.f};
+      const int c = blk * 8 + mb;  // global chunk
+      TRACE_STAMP(3 + 5 * mb);
+      // ---- phase A: epilogue of fc_0 block mb, in the shadow of fc_0 block mb+1
+      const EpiTab tb = load_epi_tab(S1, T1, 32 * mb + 4 * half);
+      unsigned hw[8], lw[8];
+      f32x16 acc_next = {0.f};
+      half8 g[8];  // fc_1 fragments of the current pair of output blocks
+      const half8 *w2 = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 1) & 3) * HALF_BYTES) + lane;
+      if (mb < 7) {
+        const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 2) & 3) * HALF_BYTES) + lane;
+        half8 fh = w[0], fl = w[X3 ? 64 : 0];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const half8 whi = w[(size_t)(2 * ks) * 64];
-        acc = mfma(whi, ahi[ks], acc);
+        for (int ks = 0; ks < 16; ++ks) {
+          const half8 ch = fh, cl = fl;
+          if (ks < 15) {
+            fh = w[(2 * ks + 2) * 64];
+            if (X3) fl = w[(2 * ks + 3) * 64];
+          } else {  // last step: start fetching fc_1's first fragments
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (X3 || !(q & 1)) g[q] = w2[q * 64];
+          }
+          acc_next = mfma(ch, ahi[ks], acc_next);
+          if (X3) {
+            acc_next = mfma(ch, alo[ks], acc_next);
+            acc_next = mfma(cl, ahi[ks], acc_next);
+          }
+          if (ks < 8) epi_slice<X3>(ks, acc_cur, tb, hw, lw, amax16);  // VALU under the MFMAs
+          if (ks >= 8) {  // two LDS-DMA pieces per step in the steps without an epilogue slice
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const int j = 2 * (ks - 8) + jj, h = 2 * c + 3 + (j >> 3);
+              if (h < N_HALVES) dma_piece(packed, s_slots, h, j & 7, wave, lane);
+            }
+          }
+          // M r r v.. | M v.. | M v.. D : everything that is independent of the
+          // accumulator chain goes into the 32-cycle gaps behind each MFMA
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (ks < 15) __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 2 : 1, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+          if (ks < 8) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (X3) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+          } else {
+            if (X3) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (X3 || !(q & 1)) g[q] = w2[q * 64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) epi_slice<X3>(i, acc_cur, tb, hw, lw, amax16);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {  // next block's first halves
+          const int h = 2 * c + 3 + (j >> 3);
+          if (h < N_HALVES) dma_piece(packed, s_slots, h, j & 7, wave, lane);
+        }
+      }
+      TRACE_STAMP(4 + 5 * mb);
+      const half8 bhi0 = words_to_frag(hw, 0), bhi1 = words_to_frag(hw, 4);
+      const half8 blo0 = words_to_frag(lw, 0), blo1 = words_to_frag(lw, 4);
+      // ---- phase B: H'[ob] += fc_1[32ob.., 32mb..32mb+31] a2', two output blocks
+      // interleaved; the next pair's fragments are fetched under the 12 MFMAs.
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        half8 cf[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cf[q] = g[q];
+        if (p < 3) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (X3 || !(q & 1)) g[q] = w2[(8 * (p + 1) + q) * 64];
+        }
+        const int o0 = 2 * p, o1 = 2 * p + 1;
+        Hs[o0] = mfma(cf[0], bhi0, Hs[o0]);
+        Hs[o1] = mfma(cf[4], bhi0, Hs[o1]);
         if (X3) {
-          const half8 wlo = w[(size_t)(2 * ks + 1) * 64];
-          acc = mfma(whi, alo[ks], acc);
-          acc = mfma(wlo, ahi[ks], acc);
+          Hs[o0] = mfma(cf[0], blo0, Hs[o0]);
+          Hs[o1] = mfma(cf[4], blo0, Hs[o1]);
+          Hs[o0] = mfma(cf[1], bhi0, Hs[o0]);
+          Hs[o1] = mfma(cf[5], bhi0, Hs[o1]);
         }
-      }
-      // a2' = relu(S1' acc + T1') for these 32 channels = 2 k-steps of GEMM2
-      half8 bhi0, bhi1, blo0, blo1;
-      cbn_relu_split<X3>(acc, S1, T1, 32 * mb + 4 * half, bhi0, bhi1, blo0, blo1, amax);
-      // ---- GEMM2 partial: H'[ob] += fc_1[32ob.., 32mb..32mb+31] a2'
-      const half8 *w2 = w + (size_t)32 * 64;
+        Hs[o0] = mfma(cf[2], bhi1, Hs[o0]);
+        Hs[o1] = mfma(cf[6], bhi1, Hs[o1]);
+        if (X3) {
+          Hs[o0] = mfma(cf[2], blo1, Hs[o0]);
+          Hs[o1] = mfma(cf[6], blo1, Hs[o1]);
+          Hs[o0] = mfma(cf[3], bhi1, Hs[o0]);
+          Hs[o1] = mfma(cf[7], bhi1, Hs[o1]);
+        }
+        if (p < 3) {
 #pragma unroll
-      for (int ob = 0; ob < 8; ++ob) {
-        {
-          const half8 whi = w2[(size_t)(4 * ob + 0) * 64];
-          Hs[ob] = mfma(whi, bhi0, Hs[ob]);
-          if (X3) {
-            const half8 wlo = w2[(size_t)(4 * ob + 1) * 64];
-            Hs[ob] = mfma(whi, blo0, Hs[ob]);
-            Hs[ob] = mfma(wlo, bhi0, Hs[ob]);
+          for (int q = 0; q < (X3 ? 8 : 4); ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
         }
-        {
-          const half8 whi = w2[(size_t)(4 * ob + 2) * 64];
-          Hs[ob] = mfma(whi, bhi1, Hs[ob]);
-          if (X3) {
-            const half8 wlo = w2[(size_t)(4 * ob + 3) * 64];
-            Hs[ob] = mfma(whi, blo1, Hs[ob]);
-            Hs[ob] = mfma(wlo, bhi1, Hs[ob]);
-          }
-        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      TRACE_STAMP(5 + 5 * mb);
+      // prefetched halves landed + everyone done with the slots refilled next
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TRACE_STAMP(6 + 5 * mb);
+      __syncthreads();
+      TRACE_STAMP(7 + 5 * mb);
+      acc_cur = acc_next;
     }
   }
 
@@ -250,8 +447,12 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
     }
   }
   part += __shfl_xor(part, 32);
+#ifdef RFD_DECODE_TRACE
+  if (tile >= 64)
+#endif
   if (half == 0) logits[pidx] = part + fc_out_b;
-  if (amax * 1.0f > 60000.f) atomicOr(status, 2u);  // f16 range exceeded
+  // 0x7bff = 65504 = largest finite f16: the round-to-zero conversion saturates there
+  if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(status, 2u);
 }
 
 }  // namespace
