@@ -33,6 +33,7 @@ struct RfdWorkspace {
   unsigned long long *fps_slots;  // FPS_RING regions of FPS_REGION_GRANULES
   unsigned *status;               // device status word (0 = OK)
   unsigned ring_pos;
+  int num_cu;                     // multiprocessor count of the device
 };
 constexpr int FPS_RING = 16;
 constexpr int FPS_MAX_WG = 256;                         // co-resident WGs/launch

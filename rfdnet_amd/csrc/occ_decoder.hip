@@ -169,8 +169,9 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 __device__ __forceinline__ void dma_piece(const half8 *__restrict__ packed, unsigned char *s_slots,
                                           int h, int j, int wave, int lane) {
   const int frag = wave * 8 + j;
+  const int hs = h >= N_HALVES ? h - N_HALVES : h;  // halves >= 80 belong to the NEXT tile (same weights)
   __builtin_amdgcn_global_load_lds(
-      (gbl_void *)(packed + ((size_t)h * HALF_FRAGS + frag) * 64 + lane),
+      (gbl_void *)(packed + ((size_t)hs * HALF_FRAGS + frag) * 64 + lane),
       (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, 0);
 }
 
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
     int n_tiles, const float *__restrict__ pts, const int *__restrict__ tile_prop,
     const int *__restrict__ tile_src, const half8 *__restrict__ packed, const float *__restrict__ fc_p_w,
     const float *__restrict__ table, const float *__restrict__ fc_out_w,
-    float fc_out_b, float *__restrict__ logits, unsigned *status) {
+    float fc_out_b, float *__restrict__ logits, unsigned *status, int tiles_per_wg) {
   constexpr bool X3 = TERMS == 3;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   float *s_tab = reinterpret_cast<float *>(smem);
@@ -200,27 +201,43 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
   float *s_wo = s_wp + H * 3;
   unsigned char *s_slots = smem + SMEM_TAB_BYTES;
 
-  const int tile = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int half = lane >> 5, n = lane & 31;
+  unsigned amax16 = 0u;
+
+  // Persistent workgroup: a contiguous run of tiles (mostly one proposal, so the
+  // table is staged rarely) and ONE uninterrupted weight ring -- the last two
+  // iterations of a tile already fetch the first three half-chunks of the next.
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
+  int cur_prop = -1;
+  bool ring_primed = false;
+  for (int tile = t_begin; tile < t_end; ++tile) {
   const int prop = tile_prop[tile];
-  if (prop < 0) return;  // padding tile (whole workgroup, before any barrier)
+  if (prop < 0) continue;  // padding tile (wave-uniform)
+  const bool has_next = tile + 1 < t_end;
 
   const size_t pidx = (size_t)tile * TILE + wave * 32 + n;
   const size_t sidx = (size_t)(tile_src ? tile_src[tile] : tile) * TILE + wave * 32 + n;
   const float px = pts[sidx * 3 + 0], py = pts[sidx * 3 + 1], pz = pts[sidx * 3 + 2];
 
-  // weights of chunk 0 (fc_0, fc_1) and chunk 1 (fc_0) in flight first
+  if (!ring_primed) {  // weights of chunk 0 (fc_0, fc_1) and chunk 1 (fc_0) in flight first
 #pragma unroll
-  for (int j = 0; j < 24; ++j) dma_piece(packed, s_slots, j >> 3, j & 7, wave, lane);
-  {  // stage the per-proposal table + first/last layer weights
+    for (int j = 0; j < 24; ++j) dma_piece(packed, s_slots, j >> 3, j & 7, wave, lane);
+  }
+  if (prop != cur_prop) {  // stage the per-proposal table (+ first/last layer weights once)
+    __syncthreads();       // everyone is done with the previous proposal's table
     const f32x4 *src = reinterpret_cast<const f32x4 *>(table + (size_t)prop * ROWS * H);
     f32x4 *dst = reinterpret_cast<f32x4 *>(s_tab);
     for (int i = t; i < ROWS * H / 4; i += 256) dst[i] = src[i];
-    for (int i = t; i < H * 3; i += 256) s_wp[i] = fc_p_w[i];
-    if (t < H) s_wo[t] = fc_out_w[t];
+    if (!ring_primed) {
+      for (int i = t; i < H * 3; i += 256) s_wp[i] = fc_p_w[i];
+      if (t < H) s_wo[t] = fc_out_w[t];
+    }
+    cur_prop = prop;
   }
+  ring_primed = true;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -239,7 +256,6 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
     }
   }
 
-  unsigned amax16 = 0u;
   half8 ahi[16], alo[16];  // B fragments of the block input, ks = 0..15
   for (int blk = 0; blk < NB; ++blk) {
     const float *S0 = s_tab + (1 + 4 * blk) * H, *T0 = S0 + H, *S1 = T0 + H, *T1 = S1 + H;
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
               const int j = 2 * (ks - 8) + jj, h = 2 * c + 3 + (j >> 3);
-              if (h < N_HALVES) dma_piece(packed, s_slots, h, j & 7, wave, lane);
+              if (h < N_HALVES || has_next) dma_piece(packed, s_slots, h, j & 7, wave, lane);
             }
           }
           // M r r v.. | M v.. | M v.. D : everything that is independent of the
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) {  // next block's first halves
           const int h = 2 * c + 3 + (j >> 3);
-          if (h < N_HALVES) dma_piece(packed, s_slots, h, j & 7, wave, lane);
+          if (h < N_HALVES || has_next) dma_piece(packed, s_slots, h, j & 7, wave, lane);
         }
       }
       TRACE_STAMP(4 + 5 * mb);
@@ -451,6 +467,7 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
   if (tile >= 64)
 #endif
   if (half == 0) logits[pidx] = part + fc_out_b;
+  }  // persistent tile loop
   // 0x7bff = 65504 = largest finite f16: the round-to-zero conversion saturates there
   if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(status, 2u);
 }
@@ -481,14 +498,18 @@ RFD_API int rfd_occ_decode(int n_tiles, const float *pts, const int *tile_prop,
   int rc = rfd_get_workspace(&ws);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  // one persistent workgroup per CU (the kernel owns the CU: 158 KiB LDS, 1 wave/SIMD)
+  const int ncu = ws->num_cu > 0 ? ws->num_cu : 256;
+  const int tiles_per_wg = ceil_div(n_tiles, ncu);
+  const int grid = ceil_div(n_tiles, tiles_per_wg);
   if (mode == RFD_OCC_MODE_F16X3) {
-    hipLaunchKernelGGL(occ_decode_kernel<3>, dim3(n_tiles), dim3(256), 0, s, n_tiles, pts,
+    hipLaunchKernelGGL(occ_decode_kernel<3>, dim3(grid), dim3(256), 0, s, n_tiles, pts,
                        tile_prop, tile_src, (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b,
-                       logits, ws->status);
+                       logits, ws->status, tiles_per_wg);
   } else if (mode == RFD_OCC_MODE_F16X1) {
-    hipLaunchKernelGGL(occ_decode_kernel<1>, dim3(n_tiles), dim3(256), 0, s, n_tiles, pts,
+    hipLaunchKernelGGL(occ_decode_kernel<1>, dim3(grid), dim3(256), 0, s, n_tiles, pts,
                        tile_prop, tile_src, (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b,
-                       logits, ws->status);
+                       logits, ws->status, tiles_per_wg);
   } else {
     rfd_set_error("rfd_occ_decode: unknown mode", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;

@@ -30,6 +30,8 @@ int rfd_get_workspace(RfdWorkspace **out) {
     RFD_CHECK(hipMalloc((void **)&w->status, 64));
     RFD_CHECK(hipMemset(w->status, 0, 64));
     w->ring_pos = 0;
+    w->num_cu = 0;
+    (void)hipDeviceGetAttribute(&w->num_cu, hipDeviceAttributeMultiprocessorCount, dev);
     g_ws[dev] = w;
   }
   *out = g_ws[dev];

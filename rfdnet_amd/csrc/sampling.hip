@@ -7,7 +7,7 @@
 // each of the m-1 serial rounds.  Here a scene is spread over G workgroups
 // whose points (xyz, running min-distance, tie rank) live in REGISTERS for the
 // whole kernel; a round is
-//   local update + per-lane argmax  ->  wave argmax (cross-lane shuffles)
+//   local update + per-lane argmax  ->  wave argmax (DPP row/bcast reductions)
 //   ->  workgroup argmax (LDS, one barrier)
 //   ->  (G > 1) all-to-all exchange of the G candidates through 8-byte
 //       {round-tag, value} granules in global memory (relaxed agent-scope
@@ -33,20 +33,24 @@ constexpr unsigned FPS_SPIN_LIMIT = 1u << 22;
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
-  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-  lo = __shfl_xor(lo, mask);
-  hi = __shfl_xor(hi, mask);
-  return ((u64)hi << 32) | lo;
+// Wave-wide unsigned max with DPP (no LDS crossbar traffic): prefix max inside
+// each 16-lane row (row_shr 1,2,4,8), row 0->1 / 2->3 (row_bcast:15), then
+// 1->2,3 (row_bcast:31); lane 63 holds the result, read back through an SGPR.
+// Lanes a control does not reach keep `old` = their own value (max identity).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_max(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return o > v ? o : v;
 }
 
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const u64 o = shfl_xor_u64(v, off);
-    v = o > v ? o : v;
-  }
-  return v;
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = dpp_max<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_max<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_max<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_max<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_max<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_max<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 struct Cand {
@@ -55,16 +59,21 @@ struct Cand {
   float x, y, z;
 };
 
-// Broadcast the candidate of the (unique) lane whose key equals the wave max.
+// Broadcast the candidate of the (unique) lane holding the wave's maximum key.
+// Two 32-bit DPP reductions (distance bits, then tie rank among the lanes that
+// hold the maximum distance) + scalar read-lanes; everything ends up in SGPRs.
 __device__ __forceinline__ Cand wave_select(const Cand &c) {
+  const unsigned hi = (unsigned)(c.key >> 32), lo = (unsigned)c.key;
+  const unsigned mh = wave_max_u32(hi);
+  const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+  const u64 m = __ballot(hi == mh && lo == ml);
+  const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
   Cand r;
-  r.key = wave_max_u64(c.key);
-  const u64 m = __ballot(c.key == r.key);
-  const int src = __ffsll((long long)m) - 1;
-  r.k = __shfl(c.k, src);
-  r.x = __shfl(c.x, src);
-  r.y = __shfl(c.y, src);
-  r.z = __shfl(c.z, src);
+  r.key = ((u64)mh << 32) | ml;
+  r.k = __builtin_amdgcn_readlane(c.k, src);
+  r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.x), src));
+  r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.y), src));
+  r.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.z), src));
   return r;
 }
 
@@ -73,6 +82,16 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_log2, int cpb) {
   const unsigned rev = bs_log2 ? (__brev(tid) >> (32 - bs_log2)) : 0u;
   return rev * (unsigned)cpb + ((unsigned)k >> bs_log2);
 }
+
+#ifdef RFD_FPS_TRACE
+#define FPS_STAMP(i)                                                                         \
+  do {                                                                                       \
+    if (j >= 100 && j < 104 && t == 0 && g == 0)                                             \
+      reinterpret_cast<unsigned long long *>(temp)[(j - 100) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define FPS_STAMP(i) do { } while (0)
+#endif
 
 template <int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
@@ -119,6 +138,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
 
   for (int j = 1; j < m; ++j) {
     const int par = j & 1;
+    FPS_STAMP(0);
     // ---- local update + argmax over this thread's points ----
     Cand c;
     c.key = 0; c.k = 0; c.x = p0x; c.y = p0y; c.z = p0z;
@@ -136,8 +156,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
       c.y = better ? py[i] : c.y;
       c.z = better ? pz[i] : c.z;
     }
+    FPS_STAMP(1);
     // ---- wave argmax, then workgroup argmax through LDS ----
     Cand w = wave_select(c);
+    FPS_STAMP(2);
     if (lane == 0) {
       s_key[par][wave] = w.key;
       s_k[par][wave] = w.k;
@@ -159,6 +181,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
       b.y = better ? s_xyz[par][q][1] : b.y;
       b.z = better ? s_xyz[par][q][2] : b.z;
     }
+    FPS_STAMP(3);
     if (G > 1) {
       // ---- publish this workgroup's candidate: 5 tagged granules ----
       u64 *mine = slots + ((size_t)g * 2 + par) * 5;
@@ -171,6 +194,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
         __hip_atomic_store(mine + t, ((u64)(unsigned)j << 32) | payload,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      FPS_STAMP(4);
       // ---- every wave gathers all G candidates (lane = workgroup) ----
       const u64 *theirs = slots + ((size_t)lane * 2 + par) * 5;
       unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
@@ -197,6 +221,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      FPS_STAMP(5);
       // a workgroup without a valid point publishes k = -1; rank is recomputed
       // from k so ties between workgroups order exactly as in the CUDA tree
       Cand o;
@@ -207,6 +232,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
       o.y = __uint_as_float(f3);
       o.z = __uint_as_float(f4);
       b = wave_select(o);
+      FPS_STAMP(6);
     }
     if (b.key == 0ull) { b.k = 0; b.x = p0x; b.y = p0y; b.z = p0z; }  // all skipped
     cx = b.x; cy = b.y; cz = b.z;  // old = dists_i[0] (:170)
@@ -216,11 +242,13 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
     }
   }
   // the CUDA kernel leaves the final min-distances in temp
+#ifndef RFD_FPS_TRACE
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = base + i * FPS_THREADS;
     if (k < n) temp[k] = td[i];
   }
+#endif
 }
 
 __global__ void gather_points_kernel(int c, int n, int m,
@@ -251,6 +279,8 @@ template <int PPT>
 int launch_fps(int nb, int n, int m, int G, int bs_log2, int cpb,
                const float *dataset, float *temp, int *idxs, float *new_xyz,
                u64 *slots, unsigned *status, hipStream_t s) {
+  // (packing the G exchanging workgroups onto one XCD -- launching 8x the blocks
+  // and using every 8th -- was measured 15 % SLOWER than letting them spread)
   hipLaunchKernelGGL(fps_kernel<PPT>, dim3(nb * G), dim3(FPS_THREADS), 0, s, n,
                      m, G, bs_log2, cpb, dataset, temp, idxs, new_xyz, slots,
                      status);
