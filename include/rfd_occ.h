@@ -148,6 +148,23 @@ int rfd_mc_emit(int K, int n, float pad_value, double iso, const float *grids,
                 const unsigned char *ebits, const int *vbase, const int *tcount,
                 const int *tbase, double *verts, int *tris, void *stream);
 
+/* ---- proposal post-processing (net_utils/ap_helper.py:131-264 parse_predictions,
+ * net_utils/nms.py:79-118, net_utils/libs.py:128-137: CPU numpy + scipy Delaunay
+ * in the reference) ---------------------------------------------------------------
+ * boxes  [b][K][7] f64: centre xyz, size (l,w,h), heading angle, in the scan frame;
+ * pts    [b][n][point_stride] f32 (xyz first); counts [b][K] = points inside each
+ * oriented box (the reference keeps boxes with >= 5, ap_helper.py:196). */
+int rfd_points_in_boxes(int b, int K, int n, int point_stride, const float *pts,
+                        const double *boxes, int *counts, void *stream);
+/* Greedy NMS on axis-aligned boxes aabb [b][K][6] f64 (x1,y1,z1,x2,y2,z2);
+ * order [b][K] i32 = box indices by descending score (sorted by the caller);
+ * `valid` selects the participating boxes, `keep` receives the picks.  use_cls: only boxes of the same class suppress each other
+ * (nms_3d_faster_samecls); old_type: overlap / area of the other box instead of
+ * IoU.  K <= 1024. */
+int rfd_nms3d(int b, int K, double iou_thr, int old_type, int use_cls, const double *aabb,
+              const int *order, const int *cls, const unsigned char *valid,
+              unsigned char *keep, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,12 +9,12 @@ the generation pipeline of the reference's demo / test drivers.
   load_weight       models/network.py:81-89 (strip `module.`, module-by-module,
                     missing keys tolerated)
 
-Proposal selection.  The reference keeps proposals with objectness > 0.5 that
-survive the CPU 3-D NMS of parse_predictions (ap_helper.py:131-264, numpy +
-scipy Delaunay) -- a "next" row of the scope table.  Until that row is built the
-selection is either 'all' (every one of the num_target proposals; BASELINE
-configs 1-4 are quoted on "256 proposals") or 'objectness' (probability
-threshold only), both evaluated on the device.
+Proposal selection.  'nms' is the reference's behaviour: proposals with
+objectness > dump_threshold that survive empty-box removal and class-aware 3-D
+NMS (parse_predictions, ap_helper.py:131-264 -- CPU numpy + scipy there, device
+kernels here, see predictions.py).  'all' keeps every one of the num_target
+proposals (BASELINE configs 1-4 are quoted on "256 proposals"); 'objectness'
+applies the probability threshold only.
 """
 import numpy as np
 import torch
@@ -71,12 +71,20 @@ class ISCNet(nn.Module):
         end_points, proposal_features = self.detection(xyz, features, end_points, True)
         return end_points, proposal_features
 
-    def select_proposals(self, end_points, selection='all'):
+    def select_proposals(self, end_points, selection='all', point_clouds=None):
         """-> (B, K, 1) int64 proposal ids (the layout of BATCH_PROPOSAL_IDs, demo.py:50-75)."""
         B, P = end_points['center'].shape[0], end_points['center'].shape[1]
         dev = end_points['center'].device
         if selection == 'all':
             return torch.arange(P, device=dev).view(1, P, 1).expand(B, P, 1).contiguous()
+        if selection == 'nms':      # the reference's behaviour (demo.py:223-234)
+            from . import predictions
+            eval_dict, parsed = predictions.parse_predictions(
+                end_points, point_clouds, self.cfg.dataset_config, getattr(self.cfg, 'eval_overrides', None))
+            end_points['parsed_predictions'] = parsed
+            end_points['pred_mask'] = eval_dict['pred_mask']
+            return predictions.get_proposal_id(end_points, eval_dict['pred_mask'],
+                                               self.cfg.config['generation']['dump_threshold'])
         if selection == 'objectness':
             assert B == 1
             thr = self.cfg.config['generation']['dump_threshold']
@@ -116,7 +124,9 @@ class ISCNet(nn.Module):
         """data['point_clouds'] (B,N,3+f) -> (end_points, proposal ids, meshes)."""
         pc = data['point_clouds']
         end_points, proposal_features = self.detect(pc)
-        ids = self.select_proposals(end_points, selection)
+        ids = self.select_proposals(end_points, selection, pc)
+        if ids.shape[1] == 0:                  # nothing survived the selection
+            return end_points, ids, []
         codes = self.object_codes(end_points, proposal_features, ids, pc)
         cls = self.cls_codes(end_points, ids)
         gen = self.completion.generator

@@ -1,0 +1,118 @@
+"""Proposal post-processing on the device: box decoding, empty-box removal and
+class-aware 3-D NMS -- the counterpart of the reference's CPU stage
+`parse_predictions` (net_utils/ap_helper.py:131-264) and of `get_proposal_id`
+(demo.py:50-75).
+
+The reference moves every head output to the host, builds 256 boxes in a Python
+double loop (:174-181), runs a scipy Delaunay point-in-hull test of all 80 000
+scan points per box (:186-197, libs.py:128-137) and a numpy greedy NMS
+(nms.py:79-118).  Here the decoding is a handful of batched float64 tensor ops
+and the two heavy parts are HIP kernels (csrc/boxes.hip); nothing leaves the
+device except the final list of proposal ids.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+
+# configs/config_files/ISCNet_test.yaml:48-60 through config_utils.py:131-149
+DEFAULT_EVAL_CONFIG = {
+    'remove_empty_box': True,        # not faster_eval
+    'use_3d_nms': True,
+    'nms_iou': 0.25,
+    'use_old_type_nms': False,
+    'cls_nms': True,
+    'per_class_proposal': True,
+    'conf_thresh': 0.05,
+}
+
+
+def _call(name, dev, *args):
+    with torch.cuda.device(dev):
+        rc = getattr(_lib.lib(), name)(*args, _lib.current_stream())
+    _lib.check(rc, name)
+
+
+def decode_boxes(end_points, dataset_config):
+    """-> centre (B,K,3), size (B,K,3) [l,w,h], heading (B,K), all float64
+    (ap_helper.py:149-166,176-179; scannet_config.py:43-53,71-73)."""
+    nh = dataset_config.num_heading_bin
+    center = end_points['center'].double()
+    heading_class = torch.argmax(end_points['heading_scores'], -1)
+    heading_residuals = end_points['heading_residuals_normalized'] * (np.pi / nh)       # float32, as the reference
+    heading_residual = torch.gather(heading_residuals, 2, heading_class.unsqueeze(-1)).squeeze(2)
+    angle = heading_class.double() * (2 * np.pi / float(nh)) + heading_residual.double()
+    angle = torch.where(angle > np.pi, angle - 2 * np.pi, angle)                        # class2angle
+    size_class = torch.argmax(end_points['size_scores'], -1)
+    mean_size = torch.from_numpy(np.asarray(dataset_config.mean_size_arr)).to(center.device)
+    size_residuals = end_points['size_residuals_normalized'] * mean_size.float().unsqueeze(0).unsqueeze(0)
+    size_residual = torch.gather(size_residuals, 2,
+                                 size_class.view(*size_class.shape, 1, 1).expand(-1, -1, 1, 3)).squeeze(2)
+    size = mean_size.double()[size_class] + size_residual.double()                       # class2size
+    return center, size, angle
+
+
+def box_corners_upright_camera(center, size, angle):
+    """get_3d_box(box_size, -heading, flip_axis_to_camera(center)) for every box
+    (box_util.py:183-198, libs.py:98-105) -> (B,K,8,3) float64."""
+    c = torch.cos(-angle)
+    s = torch.sin(-angle)
+    l, w, h = size[..., 0:1], size[..., 1:2], size[..., 2:3]
+    sx = torch.tensor([1, 1, -1, -1, 1, 1, -1, -1], dtype=torch.float64, device=center.device)
+    sy = torch.tensor([1, 1, 1, 1, -1, -1, -1, -1], dtype=torch.float64, device=center.device)
+    sz = torch.tensor([1, -1, -1, 1, 1, -1, -1, 1], dtype=torch.float64, device=center.device)
+    xc, yc, zc = l / 2 * sx, h / 2 * sy, w / 2 * sz
+    # roty(t) = [[c,0,s],[0,1,0],[-s,0,c]]
+    x = c.unsqueeze(-1) * xc + s.unsqueeze(-1) * zc
+    z = -s.unsqueeze(-1) * xc + c.unsqueeze(-1) * zc
+    cam = torch.stack([center[..., 0], -center[..., 2], center[..., 1]], -1)            # flip_axis_to_camera
+    return torch.stack([x + cam[..., 0:1], yc + cam[..., 1:2], z + cam[..., 2:3]], -1)
+
+
+@torch.no_grad()
+def parse_predictions(end_points, point_clouds, dataset_config, config=None):
+    """-> (eval_dict {'pred_mask' (B,K) uint8 tensor}, parsed dict).  Device tensors."""
+    cfg = dict(DEFAULT_EVAL_CONFIG)
+    cfg.update(config or {})
+    dev = end_points['center'].device
+    center, size, angle = decode_boxes(end_points, dataset_config)
+    B, K = angle.shape
+    corners = box_corners_upright_camera(center, size, angle)
+    pred_sem_cls = torch.argmax(end_points['sem_cls_scores'], -1)
+    sem_cls_probs = torch.softmax(end_points['sem_cls_scores'], -1)
+    obj_prob = torch.softmax(end_points['objectness_scores'], -1)[..., 1]
+
+    nonempty = torch.ones(B, K, dtype=torch.uint8, device=dev)
+    counts = None
+    if cfg['remove_empty_box']:
+        boxes = torch.cat([center, size, angle.unsqueeze(-1)], -1).contiguous()          # (B,K,7) f64
+        pc = point_clouds.contiguous()
+        counts = torch.empty(B, K, dtype=torch.int32, device=dev)
+        _call("rfd_points_in_boxes", dev, B, K, pc.shape[1], pc.shape[2], pc.data_ptr(),
+              boxes.data_ptr(), counts.data_ptr())
+        nonempty = (counts >= 5).to(torch.uint8)                                         # ap_helper.py:196
+
+    if not cfg['use_3d_nms']:
+        raise NotImplementedError("2-D NMS (use_3d_nms: False) is not used by RfD-Net's configs")
+    aabb = torch.cat([corners.min(dim=2)[0], corners.max(dim=2)[0]], -1).contiguous()    # (B,K,6)
+    keep = torch.empty(B, K, dtype=torch.uint8, device=dev)
+    order = torch.argsort(obj_prob, dim=1, descending=True, stable=True).int().contiguous()
+    cls_i = pred_sem_cls.int().contiguous()
+    valid = nonempty.contiguous()
+    _call("rfd_nms3d", dev, B, K, float(cfg['nms_iou']), int(bool(cfg['use_old_type_nms'])),
+          int(bool(cfg['cls_nms'])), aabb.data_ptr(), order.data_ptr(), cls_i.data_ptr(),
+          valid.data_ptr(), keep.data_ptr())
+    parsed = {'pred_corners_3d_upright_camera': corners, 'sem_cls_probs': sem_cls_probs,
+              'obj_prob': obj_prob, 'pred_sem_cls': pred_sem_cls,
+              'box_params': torch.cat([center, size, angle.unsqueeze(-1)], -1),
+              'points_in_box': counts}
+    return {'pred_mask': keep}, parsed
+
+
+def get_proposal_id(end_points, pred_mask, dump_conf_thresh):
+    """Proposals with objectness probability above the threshold that survived
+    NMS, in index order (demo.py:50-75) -> (1, K', 1) int64."""
+    prob = torch.softmax(end_points['objectness_scores'], dim=2)[..., 1]
+    assert prob.shape[0] == 1, "the reference's generation path runs batch size 1"
+    sel = (prob[0] > dump_conf_thresh) & (pred_mask[0] != 0)
+    return torch.nonzero(sel).view(1, -1, 1)

@@ -283,6 +283,63 @@ def make_gen():
     np.savez_compressed(os.path.join(HERE, "F_GEN.npz"), **out)
 
 
+def make_nms():
+    """F-NMS: the reference's own parse_predictions (net_utils/ap_helper.py:131-264,
+    run on CPU with Tensor.cuda patched to the identity) + get_proposal_id logic
+    (demo.py:50-75) on the proposal head outputs stored in F_NET.npz."""
+    import torch
+    mount_reference()
+    tm = sys.modules['trimesh']
+    ex = ns('trimesh.exchange')
+    bx = ns('trimesh.exchange.binvox')
+    bx.voxelize_mesh = None
+    tm.exchange = ex
+    ex.binvox = bx
+    ap = importlib.import_module('net_utils.ap_helper')
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    fx = np.load(os.path.join(HERE, "F_NET.npz"))
+    seed, n_raw, n_pts = (int(v) for v in fx["pc_seed"])
+    pc = synthetic.synthetic_scene(seed=seed, n_raw=n_raw, n_points=n_pts)
+    means = np.load(REF + "/datasets/scannet/scannet_means.npz")
+    mean_size_arr = means[means.files[0]]
+    from rfdnet_amd.iscnet.config import ScannetConfig
+
+    class DC(ScannetConfig):                       # the reference's class2angle / class2size (scannet_config.py:43-73)
+        def class2angle(self, pred_cls, residual, to_label_format=True):
+            angle = pred_cls * (2 * np.pi / float(self.num_heading_bin)) + residual
+            if to_label_format and angle > np.pi:
+                angle = angle - 2 * np.pi
+            return angle
+
+        def class2size(self, pred_cls, residual):
+            return self.mean_size_arr[pred_cls, :] + residual
+
+    dc = DC(mean_size_arr)
+    est = {k[5:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("prop_") and k not in
+           ("prop_names", "prop_shapes", "prop_features", "prop_aggregated_vote_inds")}
+    # make the objectness spread over both sides of 0.5 and classes collide so NMS has work to do
+    rng = np.random.default_rng(3)
+    est['objectness_scores'] = torch.from_numpy(rng.normal(0, 2.0, (1, 256, 2)).astype(np.float32))
+    est['size_residuals_normalized'] = est['size_residuals_normalized'] * 0.2
+    out = {'mean_size_arr': mean_size_arr, 'objectness_scores': est['objectness_scores'].numpy(),
+           'size_residuals_normalized': est['size_residuals_normalized'].numpy()}
+    for tag, cfgd in (("default", {}), ("nocls", {'cls_nms': False}), ("old", {'use_old_type_nms': True}),
+                      ("keepempty", {'remove_empty_box': False})):
+        config = {'remove_empty_box': True, 'use_3d_nms': True, 'nms_iou': 0.25, 'use_old_type_nms': False,
+                  'cls_nms': True, 'per_class_proposal': True, 'conf_thresh': 0.05, 'dataset_config': dc}
+        config.update(cfgd)
+        eval_dict, parsed = ap.parse_predictions(est, {'point_clouds': torch.from_numpy(pc[None])}, config)
+        out[tag + '_pred_mask'] = eval_dict['pred_mask']
+        if tag == "default":
+            out['corners'] = parsed['pred_corners_3d_upright_camera']
+            out['obj_prob'] = parsed['obj_prob']
+            prob = torch.softmax(est['objectness_scores'], dim=2)[..., 1].numpy()
+            sel = (prob[0] > 0.5) * eval_dict['pred_mask'][0]
+            out['proposal_ids'] = np.where(sel.astype(bool))[0]
+        print("F_NMS", tag, int(eval_dict['pred_mask'].sum()))
+    np.savez_compressed(os.path.join(HERE, "F_NMS.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["dec", "mise", "grid"]
     for w in what:
