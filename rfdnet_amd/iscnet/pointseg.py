@@ -64,6 +64,26 @@ class PointNetEncoder(nn.Module):
         if feature_transform:
             self.fstn = STNkd(k=64)
 
+    def forward_with_pointfeat(self, x):
+        """(global feature (B,1024), trans, trans_feat, per-point features (B,64,N))"""
+        B, D, N = x.size()
+        trans = self.stn(x)
+        x = x.transpose(2, 1)
+        if D > 3:
+            x = torch.cat([torch.bmm(x[..., :3], trans), x[..., 3:]], dim=2)
+        else:
+            x = torch.bmm(x, trans)
+        x = F.relu(self.bn1(self.conv1(x.transpose(2, 1))))
+        trans_feat = None
+        if self.feature_transform:
+            trans_feat = self.fstn(x)
+            x = torch.bmm(x.transpose(2, 1), trans_feat).transpose(2, 1)
+        pointfeat = x
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = self.bn3(self.conv3(x))
+        x = torch.max(x, 2)[0]
+        return x, trans, trans_feat, pointfeat
+
     def forward(self, x):
         B, D, N = x.size()
         trans = self.stn(x)
@@ -102,6 +122,8 @@ class PointSeg(nn.Module):
 
     def forward(self, x):
         B, _, n_pts = x.size()
+        if not self.training:
+            return self._forward_factored(x)
         x, _, trans_feat = self.feat(x)
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
@@ -109,3 +131,26 @@ class PointSeg(nn.Module):
         x = self.conv4(x).transpose(2, 1).contiguous()
         x = F.log_softmax(x.view(-1, self.k), dim=-1).view(B, n_pts, self.k)
         return x, trans_feat
+
+    def _forward_factored(self, x):
+        """Inference path: the 1024 global-feature channels of the 1088-channel
+        head input are identical for all points of a proposal, so their share of
+        conv1 is one vector per proposal; only the 64 point-feature channels go
+        through the per-point GEMM (conv1: 1088x512 -> 64x512 MACs per point)."""
+        B, _, n_pts = x.size()
+        enc = self.feat
+        gf = enc.global_feat
+        enc.global_feat = True                      # ask the encoder for the un-tiled global vector
+        try:
+            g, _, trans_feat, pointfeat = enc.forward_with_pointfeat(x)
+        finally:
+            enc.global_feat = gf
+        w = self.conv1.weight[:, :, 0]
+        head = F.linear(g, w[:, :1024], self.conv1.bias)                       # (B,512)
+        y = F.conv1d(pointfeat, w[:, 1024:].unsqueeze(-1)) + head.unsqueeze(-1)
+        y = F.relu(self.bn1(y))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = F.relu(self.bn3(self.conv3(y)))
+        y = self.conv4(y).transpose(2, 1).contiguous()
+        y = F.log_softmax(y.view(-1, self.k), dim=-1).view(B, n_pts, self.k)
+        return y, trans_feat

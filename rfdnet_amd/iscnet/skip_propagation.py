@@ -4,6 +4,7 @@ box, align to the box frame, mask with PointSeg and encode to the shape code
 (r = 1 m, 1024 samples) and the grouping are HIP kernels; the dense nets are
 torch/rocBLAS."""
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from ..pointnet2_ops.pointnet2_modules import STN_Group
@@ -42,7 +43,14 @@ class SkipPropagation(nn.Module):
         inp = inp.permute(0, 2, 3, 1).contiguous().view(B * K, P, -1)
         seg_pred, _ = self.point_seg(inp.transpose(1, 2).contiguous())
         mask = torch.argmax(seg_pred.view(B * K * P, 2), dim=1).view(B * K, P, 1)
-        box = box_feature.transpose(1, 2).contiguous().view(B * K, 1, -1).expand(-1, P, -1)
-        enc_in = torch.cat([inp, box], dim=2) * mask.float()
-        codes = self.encoder(enc_in)
+        # encoder input = cat([points, box feature repeated over the points]) * mask.
+        # The 128 box-feature channels are one vector per proposal, so their share
+        # of fc_pos is a per-proposal vector scaled by the per-point 0/1 mask.
+        maskf = mask.float()                                                     # (B*K,P,1)
+        enc = self.encoder
+        d = inp.shape[2]
+        box = box_feature.transpose(1, 2).contiguous().view(B * K, -1)          # (B*K,128)
+        w = enc.fc_pos.weight
+        pos = F.linear(inp * maskf, w[:, :d], enc.fc_pos.bias) + maskf * F.linear(box, w[:, d:]).unsqueeze(1)
+        codes = enc.forward_factored(pos)
         return codes.view(B, K, -1).transpose(1, 2)
