@@ -36,8 +36,8 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=80000)
     ap.add_argument("--resolution0", type=int, default=32)
     ap.add_argument("--upsampling-steps", type=int, default=1)
@@ -93,21 +93,46 @@ class DecodeTimer(object):
                 "tflops": float(np.sum(pts)) * FLOP_PER_QUERY / (float(np.sum(ms)) * 1e-3) / 1e12}
 
 
-def run_scene(net, pc, host_bufs):
+class MeshSink(object):
+    """Meshes end up in (pinned) host memory like the reference's trimesh objects
+    (generator.py:181-183).  The D2H copy of scene i runs on its own stream and
+    overlaps the reconstruction of scene i+1 (two host buffer sets, alternating);
+    everything is drained before the clock stops."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device)
+        self.bufs = [[None, None], [None, None]]
+        self.turn = 0
+
+    def push(self, v, f):
+        nv, nt = int(v.shape[0]), int(f.shape[0])
+        if not nv:
+            return
+        for b in self.bufs:          # pinned allocation is slow: size BOTH sets at first use (warm-up)
+            if b[0] is None or b[0].shape[0] < nv:
+                b[0] = torch.empty(int(nv * 1.5) + 1, 3, dtype=torch.float64).pin_memory()
+            if b[1] is None or b[1].shape[0] < nt:
+                b[1] = torch.empty(int(nt * 1.5) + 1, 3, dtype=torch.int32).pin_memory()
+        hb = self.bufs[self.turn]
+        self.turn ^= 1
+        done = torch.cuda.Event()
+        done.record()                                   # meshes complete on the compute stream
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(done)
+            hb[0][:nv].copy_(v, non_blocking=True)
+            hb[1][:nt].copy_(f, non_blocking=True)
+        v.record_stream(self.stream)
+        f.record_stream(self.stream)
+
+    def drain(self):
+        self.stream.synchronize()
+
+
+def run_scene(net, pc, sink):
     _, _, meshes = net.generate({'point_clouds': pc}, selection='all')
-    # end of the reference's timed region: meshes live on the host (generator.py:181-183)
-    nv = sum(int(m.vertices.shape[0]) for m in meshes)
-    nt = sum(int(m.faces.shape[0]) for m in meshes)
-    if nv:
-        v = torch.cat([m.vertices for m in meshes])
-        f = torch.cat([m.faces for m in meshes])
-        if host_bufs[0] is None or host_bufs[0].shape[0] < nv:
-            host_bufs[0] = torch.empty(int(nv * 1.2) + 1, 3, dtype=torch.float64).pin_memory()
-        if host_bufs[1] is None or host_bufs[1].shape[0] < nt:
-            host_bufs[1] = torch.empty(int(nt * 1.2) + 1, 3, dtype=torch.int32).pin_memory()
-        host_bufs[0][:nv].copy_(v, non_blocking=True)
-        host_bufs[1][:nt].copy_(f, non_blocking=True)
-    return len(meshes), nv, nt, net.completion.generator.stats.get('n_queries', 0)
+    v, f, _, _ = net.completion.generator.last_buffers       # all K meshes: one vertex / one face buffer
+    sink.push(v, f)
+    return len(meshes), int(v.shape[0]), int(f.shape[0]), net.completion.generator.stats.get('n_queries', 0)
 
 
 def cpu_baseline(args, n_queries_per_scene, n_prop):
@@ -197,10 +222,11 @@ def main():
     # two scenes per rank, resident in HBM before timing
     scenes = [torch.from_numpy(synthetic.synthetic_scene(seed=10 + 100 * rank + s, n_points=args.points)[None])
               .to(device) for s in range(2)]
-    host_bufs = [None, None]
+    sink = MeshSink(device)
 
     for w in range(args.warmup):
-        run_scene(net, scenes[w % 2], host_bufs)
+        run_scene(net, scenes[w % 2], sink)
+    sink.drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -209,8 +235,9 @@ def main():
     t0 = time.perf_counter()
     n_meshes = nv = nt = nq = 0
     for s in range(args.steps):
-        a, b, c, d = run_scene(net, scenes[s % 2], host_bufs)
+        a, b, c, d = run_scene(net, scenes[s % 2], sink)
         n_meshes += a; nv += b; nt += c; nq += d
+    sink.drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -152,15 +152,13 @@ class Generator3D(object):
         thr = self.logit_threshold()
         n = grids.shape[1]
         box_size = 1 + self.padding
-        out = []
-        for v, f in marching_cubes_batch(grids, thr, pad_value=-1e6):
-            # generator.py:163-168 with the library's 0.5 offset already removed:
-            # undo padding, normalise to the unit cube, scale to the bounding box
-            v = v - 1
-            v = v / (n - 1)
-            v = box_size * (v - 0.5)
-            out.append(Mesh(v, f))
-        return out
+        v, f, vend, tend = marching_cubes_batch(grids, thr, pad_value=-1e6, return_flat=True)
+        # generator.py:163-168 (the library's 0.5 offset is not present here):
+        # undo padding, normalise to the unit cube, scale to the bounding box --
+        # once on the buffer holding all K meshes, then split into views
+        v = box_size * ((v - 1) / (n - 1) - 0.5)
+        self.last_buffers = (v, f, vend, tend)
+        return [Mesh(v[vend[k]:vend[k + 1]], f[tend[k]:tend[k + 1]]) for k in range(len(vend) - 1)]
 
     def extract_mesh(self, occ_hat, z=None, c=None):
         g = torch.as_tensor(occ_hat, dtype=torch.float32)

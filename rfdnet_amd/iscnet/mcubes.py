@@ -14,10 +14,12 @@ def _call(name, dev, *args):
 
 
 @torch.no_grad()
-def marching_cubes_batch(grids, threshold, pad_value=-1e6):
+def marching_cubes_batch(grids, threshold, pad_value=-1e6, return_flat=False):
     """grids (K,n,n,n) f32 device tensor -> list of K (vertices (nv,3) f64,
     faces (nt,3) i32) device tensors.  Vertex coordinates are in the index
-    space of the PADDED grid (original grid point i at i + 1)."""
+    space of the PADDED grid (original grid point i at i + 1).
+    return_flat=True -> (all vertices, all faces, vertex bounds, face bounds):
+    one buffer each for the K meshes, split points as Python lists."""
     assert grids.is_cuda and grids.dtype == torch.float32 and grids.dim() == 4
     grids = grids.contiguous()
     K, n = grids.shape[0], grids.shape[1]
@@ -46,4 +48,6 @@ def marching_cubes_batch(grids, threshold, pad_value=-1e6):
         _call("rfd_mc_emit", dev, K, n, float(pad_value), float(threshold), grids.data_ptr(),
               ebits.data_ptr(), vbase.data_ptr(), tcount.data_ptr(), tbase.data_ptr(),
               verts.data_ptr(), tris.data_ptr())
+    if return_flat:
+        return verts[:nv], tris[:nt], vend, tend
     return [(verts[vend[k]:vend[k + 1]], tris[tend[k]:tend[k + 1]]) for k in range(K)]
