@@ -105,6 +105,18 @@ class MeshSink(object):
         self.turn = 0
 
     def push(self, v, f):
+        """Queue the meshes of the scene just finished; the copy is STARTED by
+        start_pending() once the next scene is past its backbone (the
+        multi-workgroup FPS exchanges 8-byte granules through memory every round
+        and runs 70 % slower with a PCIe copy in flight; the MFMA-bound decoder
+        does not care)."""
+        self.pending = (v, f)
+
+    def start_pending(self):
+        if getattr(self, "pending", None) is None:
+            return
+        v, f = self.pending
+        self.pending = None
         nv, nt = int(v.shape[0]), int(f.shape[0])
         if not nv:
             return
@@ -125,14 +137,24 @@ class MeshSink(object):
         f.record_stream(self.stream)
 
     def drain(self):
+        self.start_pending()
         self.stream.synchronize()
 
 
 def run_scene(net, pc, sink):
-    _, _, meshes = net.generate({'point_clouds': pc}, selection='all')
-    v, f, _, _ = net.completion.generator.last_buffers       # all K meshes: one vertex / one face buffer
+    """ISCNet.generate(selection='all') stage by stage (network.py), with the
+    previous scene's mesh copy released after the backbone."""
+    with torch.no_grad():
+        end_points, proposal_features = net.detect(pc)
+        sink.start_pending()
+        ids = net.select_proposals(end_points, 'all', pc)
+        codes = net.object_codes(end_points, proposal_features, ids, pc)
+        cls = net.cls_codes(end_points, ids)
+        gen = net.completion.generator
+        meshes = gen.generate_mesh(codes, cls)
+    v, f, _, _ = gen.last_buffers                              # all K meshes: one vertex / one face buffer
     sink.push(v, f)
-    return len(meshes), int(v.shape[0]), int(f.shape[0]), net.completion.generator.stats.get('n_queries', 0)
+    return len(meshes), int(v.shape[0]), int(f.shape[0]), gen.stats.get('n_queries', 0)
 
 
 def cpu_baseline(args, n_queries_per_scene, n_prop):
