@@ -61,17 +61,44 @@ class ResnetPointnet(nn.Module):
         their per-point halves run as one GEMM.  `pos_term` = fc_pos output
         (B,T,2*hidden), passed in because its own input is factored by the caller."""
         import torch.nn.functional as F
+        from .. import gemm
         h = self.block_0.size_h
-        net = self.block_0(pos_term)
-        for i in range(1, 5):
+        B, T, _ = pos_term.shape
+        fast = gemm.usable(B * T, 2 * h, 2 * h, pos_term.view(B * T, -1)) and h % 128 == 0
+
+        def stacked(i):
+            """[fc_0 ; shortcut] weights of block i, split into the per-point and the
+            pooled column halves (cached per parameter version)."""
             blk = getattr(self, 'block_%d' % i)
+            key = (i, blk.fc_0.weight._version, blk.shortcut.weight._version, blk.fc_0.bias._version,
+                   blk.fc_0.weight.data_ptr())
+            c = self.__dict__.setdefault('_stack_cache', {})
+            if c.get(i, (None,))[0] != key:
+                w = torch.cat([blk.fc_0.weight, blk.shortcut.weight], 0).detach()
+                bias = torch.cat([blk.fc_0.bias, torch.zeros_like(blk.fc_0.bias)]).detach()
+                c[i] = (key, w[:, :h].contiguous(), w[:, h:].contiguous(), bias, w.contiguous())
+            return blk, c[i]
+
+        # block 0: both halves of its 2h-wide input are per-point
+        blk, (_, _, _, bias0, w_full) = stacked(0)
+        if fast:
+            x2 = pos_term.view(B * T, 2 * h)
+            both = gemm.linear(x2, w_full, bias=bias0, relu_in=True)                       # (M,2h)
+            net = gemm.linear(both[:, :h], blk.fc_1.weight, bias=blk.fc_1.bias, residual=both[:, h:],
+                              relu_in=True).view(B, T, h)
+        else:
+            net = self.block_0(pos_term)
+        for i in range(1, 5):
+            blk, (_, w_pt, w_pl, bias, _) = stacked(i)
             pooled = torch.relu(self.pool(net, dim=1))                       # (B,h)
-            a = torch.relu(net)                                              # (B,T,h)
-            w_pt = torch.cat([blk.fc_0.weight[:, :h], blk.shortcut.weight[:, :h]], 0)      # (2h,h)
-            w_pl = torch.cat([blk.fc_0.weight[:, h:], blk.shortcut.weight[:, h:]], 0)
-            bias = torch.cat([blk.fc_0.bias, torch.zeros_like(blk.fc_0.bias)])
-            both = F.linear(a, w_pt) + F.linear(pooled, w_pl, bias).unsqueeze(1)           # (B,T,2h)
-            dx = blk.fc_1(torch.relu(both[..., :h]))
-            net = both[..., h:] + dx
+            gb = F.linear(pooled, w_pl, bias)                                # (B,2h): once per proposal
+            if fast:
+                both = gemm.linear(net.view(B * T, h), w_pt, gbias=gb, rows_per_group=T, relu_in=True)
+                net = gemm.linear(both[:, :h], blk.fc_1.weight, bias=blk.fc_1.bias, residual=both[:, h:],
+                                  relu_in=True).view(B, T, h)
+            else:
+                both = F.linear(torch.relu(net), w_pt) + gb.unsqueeze(1)     # (B,T,2h)
+                dx = blk.fc_1(torch.relu(both[..., :h]))
+                net = both[..., h:] + dx
         net = self.pool(net, dim=1)
         return self.fc_c(self.actvn(net))

@@ -74,6 +74,17 @@ def main():
             res["decode_%s_TFLOPs" % name] = K * T * 1312768 / t / 1e9
             res["decode_%s_Mpts_s" % name] = K * T / t / 1e3
         res["fold_ms"] = timeit(lambda: dec.fold(z, c))
+    from rfdnet_amd import gemm
+    for (M, N, K) in ((262144, 1024, 1024), (262144, 1024, 512), (262144, 512, 512)):
+        xa = torch.randn(M, K, device="cuda")
+        wa = torch.randn(N, K, device="cuda") / K ** 0.5
+        oa = torch.empty(M, N, device="cuda")
+        t = timeit(lambda: gemm.linear(xa, wa, relu_in=True, out=oa), warm=1, it=3)
+        res["gemm_f16x3_%dx%dx%d_ms" % (M, N, K)] = t
+        res["gemm_f16x3_%dx%dx%d_TFLOPs" % (M, N, K)] = 2.0 * M * N * K / t / 1e9
+        t2 = timeit(lambda: torch.mm(torch.relu(xa), wa.t(), out=oa), warm=1, it=3)
+        res["torch_fp32_%dx%dx%d_ms" % (M, N, K)] = t2
+        del xa, wa, oa
     _lib.device_status()
     print(json.dumps(res, indent=1))
 
