@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--resolution0", type=int, default=32)
     ap.add_argument("--upsampling-steps", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="scenes reconstructed concurrently per GPU (one host thread + HIP stream + model "
+                         "replica each); a step = one such batch")
     ap.add_argument("--mode", choices=["f16x3", "f16x1"], default="f16x3",
                     help="decoder arithmetic; f16x3 is the parity mode (1e-4 on logits)")
     return ap.parse_args()
@@ -83,14 +86,26 @@ class DecodeTimer(object):
             return out
         dec.decode_tiles = wrapped
 
-    def summary(self):
-        if not self.records:
-            return None
-        ms = [e0.elapsed_time(e1) for _, e0, e1 in self.records]
-        pts = [n for n, _, _ in self.records]
-        return {"launches": len(ms), "avg_ms": float(np.mean(ms)), "total_ms": float(np.sum(ms)),
-                "points": int(np.sum(pts)),
-                "tflops": float(np.sum(pts)) * FLOP_PER_QUERY / (float(np.sum(ms)) * 1e-3) / 1e12}
+    def intervals(self, base):
+        """[(start_ms, end_ms, points)] of every recorded launch relative to `base`."""
+        return [(base.elapsed_time(e0), base.elapsed_time(e1), n) for n, e0, e1 in self.records]
+
+
+def union_ms(intervals):
+    """Length of the union of [start, end] intervals: with several scenes in flight
+    two decoder launches can be resident at once; the time 'the decoder' runs is the
+    union, not the sum, of their spans."""
+    tot, cur_s, cur_e = 0.0, None, None
+    for s0, e0, _ in sorted(intervals):
+        if cur_e is None or s0 > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = s0, e0
+        else:
+            cur_e = max(cur_e, e0)
+    if cur_e is not None:
+        tot += cur_e - cur_s
+    return tot
 
 
 class MeshSink(object):
@@ -230,47 +245,69 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # RFD_BENCH_ONE_DEVICE=1: dry run of the N>1 code path on a 1-GPU box (all ranks
+    # on cuda:0, gloo for the statistics exchange) -- never used for reported numbers
+    one_dev = os.environ.get("RFD_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")          # RCCL on ROCm
+        dist.init_process_group(backend="gloo" if one_dev else "nccl")   # "nccl" = RCCL over xGMI
     assert world == args.gpus or world == 1, (world, args.gpus)
 
+    from concurrent.futures import ThreadPoolExecutor
     from rfdnet_amd import _lib, synthetic
-    net = build_net(args, device)
-    timer = DecodeTimer(net.completion.decoder)
-    # two scenes per rank, resident in HBM before timing
-    scenes = [torch.from_numpy(synthetic.synthetic_scene(seed=10 + 100 * rank + s, n_points=args.points)[None])
-              .to(device) for s in range(2)]
-    sink = MeshSink(device)
+    S = max(1, args.in_flight)
+    # one model replica, stream, mesh sink and decoder timer per in-flight scene
+    nets = [build_net(args, device) for _ in range(S)]
+    timers = [DecodeTimer(n.completion.decoder) for n in nets]
+    streams = [torch.cuda.Stream(device) for _ in range(S)]
+    sinks = [MeshSink(device) for _ in range(S)]
+    # two scenes per worker, resident in HBM before timing
+    scenes = [[torch.from_numpy(synthetic.synthetic_scene(seed=10 + 100 * rank + 7 * w + s, n_points=args.points)[None])
+               .to(device) for s in range(2)] for w in range(S)]
+    torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        run_scene(net, scenes[w % 2], sink)
-    sink.drain()
+    def worker(w, n_steps, first):
+        torch.cuda.set_device(device)
+        tot = [0, 0, 0, 0]
+        with torch.cuda.stream(streams[w]):
+            for s in range(n_steps):
+                r = run_scene(nets[w], scenes[w][(first + s) % 2], sinks[w])
+                tot = [a + b for a, b in zip(tot, r)]
+            sinks[w].drain()
+            streams[w].synchronize()
+        return tot
+
+    pool = ThreadPoolExecutor(max_workers=S)
+    list(pool.map(lambda w: worker(w, args.warmup, 0), range(S)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    for tm in timers:
+        tm.enabled = True
+    base_evt = torch.cuda.Event(enable_timing=True)
+    base_evt.record()
     t0 = time.perf_counter()
-    n_meshes = nv = nt = nq = 0
-    for s in range(args.steps):
-        a, b, c, d = run_scene(net, scenes[s % 2], sink)
-        n_meshes += a; nv += b; nt += c; nq += d
-    sink.drain()
+    res = list(pool.map(lambda w: worker(w, args.steps, args.warmup), range(S)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    for tm in timers:
+        tm.enabled = False
     _lib.device_status()
+    n_meshes, nv, nt, nq = (sum(r[i] for r in res) for i in range(4))
+    n_scenes = args.steps * S
 
     from rfdnet_amd import sharding
-    dsum = timer.summary() or {"launches": 0, "avg_ms": 0.0, "total_ms": 0.0, "points": 0, "tflops": 0.0}
-    stats = sharding.pack_stats(steps=args.steps, elapsed_s=elapsed, n_meshes=n_meshes, n_vertices=nv,
+    ivals = [iv for tm in timers for iv in tm.intervals(base_evt)]
+    dsum = {"total_ms": union_ms(ivals), "points": sum(iv[2] for iv in ivals), "launches": len(ivals)}
+    stats = sharding.pack_stats(steps=n_scenes, elapsed_s=elapsed, n_meshes=n_meshes, n_vertices=nv,
                                 n_triangles=nt, n_queries=nq, decode_ms=dsum["total_ms"],
                                 decode_points=dsum["points"], decode_launches=dsum["launches"])
     gathered = sharding.gather_stats(stats, device, dist)     # the path's only exchange step
@@ -298,7 +335,9 @@ def main():
                        "proposals_per_scene": int(gathered[:, 2].sum() / scenes_total),
                        "queries_per_scene": int(gathered[:, 5].sum() / scenes_total),
                        "vertices_per_scene": int(gathered[:, 3].sum() / scenes_total),
-                       "parallelism": "scenes sharded 1/GPU, dp%d" % world},
+                       "scenes_in_flight_per_gpu": S,
+                       "scenes_per_step": S * world,
+                       "parallelism": "scenes sharded across GPUs, dp%d; %d scenes in flight per GPU" % (world, S)},
             "roofline": {"bound": "mfma", "kernel": "occ_decode_kernel<%d>" % (3 if args.mode == "f16x3" else 1),
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
@@ -308,7 +347,7 @@ def main():
                          "note": "algorithmic FLOPs (1 312 768 per query point); f16x3 issues 3x that on the MFMA pipe"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, int(gathered[0, 5] / args.steps), int(gathered[0, 2] / args.steps))
+            out["cpu_baseline"] = cpu_baseline(args, int(gathered[0, 5] / n_scenes), int(gathered[0, 2] / n_scenes))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 
 #define RFD_API extern "C" __attribute__((visibility("default")))
 
@@ -32,7 +33,7 @@ void rfd_set_error(const char *where, hipError_t e);
 struct RfdWorkspace {
   unsigned long long *fps_slots;  // FPS_RING regions of FPS_REGION_GRANULES
   unsigned *status;               // device status word (0 = OK)
-  unsigned ring_pos;
+  std::atomic<unsigned> ring_pos;   // callers may come from several host threads / streams
   int num_cu;                     // multiprocessor count of the device
 };
 constexpr int FPS_RING = 16;

@@ -29,7 +29,7 @@ int rfd_get_workspace(RfdWorkspace **out) {
                         sizeof(unsigned long long) * (size_t)FPS_RING * FPS_REGION_GRANULES));
     RFD_CHECK(hipMalloc((void **)&w->status, 64));
     RFD_CHECK(hipMemset(w->status, 0, 64));
-    w->ring_pos = 0;
+    w->ring_pos.store(0);
     w->num_cu = 0;
     (void)hipDeviceGetAttribute(&w->num_cu, hipDeviceAttributeMultiprocessorCount, dev);
     g_ws[dev] = w;

@@ -320,7 +320,7 @@ int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
     const int nb = (b - b0) < batches_per_launch ? (b - b0) : batches_per_launch;
     u64 *slots = nullptr;
     if (G > 1) {
-      slots = ws->fps_slots + (size_t)(ws->ring_pos++ % FPS_RING) * FPS_REGION_GRANULES;
+      slots = ws->fps_slots + (size_t)(ws->ring_pos.fetch_add(1) % FPS_RING) * FPS_REGION_GRANULES;
       RFD_CHECK(hipMemsetAsync(slots, 0, sizeof(u64) * (size_t)nb * G * 10, s));
     }
     const float *ds = dataset + (size_t)b0 * n * 3;

@@ -29,6 +29,8 @@ def pack_stats(**kw):
 def gather_stats(stats, device, dist=None):
     """stats: list of len(STAT_FIELDS) floats of THIS rank -> (world, n) float64
     array identical on every rank.  dist=None or world 1 => no communication."""
+    if dist is not None and dist.is_initialized() and dist.get_backend() == "gloo":
+        device = torch.device("cpu")          # CPU tests / single-GPU dry runs of the N>1 path
     vec = torch.tensor(stats, dtype=torch.float64, device=device)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return vec.view(1, -1).cpu().numpy()
