@@ -211,11 +211,19 @@ def cpu_baseline(args, n_queries_per_scene, n_prop):
     synthetic.load_seeded(dec, 1)
     blob = oracle.decoder_param_blob({k: v.numpy() for k, v in dec.state_dict().items()})
     rng = np.random.default_rng(0)
-    n_s = 16384
-    p = ((rng.random((1, n_s, 3)) - 0.5) * 1.1).astype(np.float32)
-    t0 = time.time()
-    oracle.decoder_cbn(blob, p, np.zeros((1, 32), np.float32), rng.normal(size=(1, 512)).astype(np.float32))
-    t_dec_s = time.time() - t0
+    zc = np.zeros((1, 32), np.float32)
+    cc = rng.normal(size=(1, 512)).astype(np.float32)
+
+    def dec_time(n):
+        p = ((rng.random((1, n, 3)) - 0.5) * 1.1).astype(np.float32)
+        t0 = time.time()
+        oracle.decoder_cbn(blob, p, zc, cc)
+        return time.time() - t0
+
+    dec_time(8192)                                   # spin up the OpenMP team
+    t_cal = max(dec_time(32768), 1e-4)
+    n_s = int(min(4 << 20, max(65536, 32768 * 10.0 / t_cal)))   # ~10 s of CPU work
+    t_dec_s = dec_time(n_s)
     t['decode_extrapolated'] = t_dec_s * n_queries_per_scene / n_s
     # MISE: octree bookkeeping for a sample of proposals on an analytic field
     t0 = time.time()
