@@ -38,6 +38,22 @@ class _TNet(nn.Module):
         return x.view(-1, k, k)
 
 
+    def forward_rows(self, x, P):
+        """Row-major inference path: x (B*P, k_in) -> (B, k_out, k_out).  BN folded,
+        the wide layers on the split-precision GEMM with fused bias + ReLU."""
+        from ..fold_bn import folded, linear_rows
+        h = linear_rows(x, *folded(self.conv1, self.bn1), relu=True)
+        h = linear_rows(h, *folded(self.conv2, self.bn2), relu=True)
+        h = linear_rows(h, *folded(self.conv3, self.bn3), relu=True)
+        g = h.view(-1, P, h.shape[1]).max(dim=1)[0]
+        g = linear_rows(g, *folded(self.fc1, self.bn4), relu=True)
+        g = linear_rows(g, *folded(self.fc2, self.bn5), relu=True)
+        g = F.linear(g, self.fc3.weight, self.fc3.bias)
+        k = self._k_out
+        g = g + torch.eye(k, device=g.device, dtype=g.dtype).view(1, k * k)
+        return g.view(-1, k, k)
+
+
 class STN3d(_TNet):
     def __init__(self, channel):
         super().__init__(channel, 3)
@@ -131,6 +147,41 @@ class PointSeg(nn.Module):
         x = self.conv4(x).transpose(2, 1).contiguous()
         x = F.log_softmax(x.view(-1, self.k), dim=-1).view(B, n_pts, self.k)
         return x, trans_feat
+
+    def forward_rows(self, inp):
+        """Inference path on ROW-major points: inp (B, P, D) with xyz first ->
+        (log-probabilities (B,P,k), trans_feat).  Same function as forward() on
+        inp.transpose(1, 2); BatchNorms folded into the layers, the global-feature
+        share of the head's first layer reduced to one vector per proposal, wide
+        layers on the split-precision GEMM."""
+        from ..fold_bn import folded, linear_rows
+        B, P, D = inp.shape
+        enc = self.feat
+        x = inp.reshape(B * P, D)
+        trans = enc.stn.forward_rows(x, P)                                   # (B,3,3)
+        xyz = torch.bmm(inp[..., :3], trans)
+        x = (torch.cat([xyz, inp[..., 3:]], dim=2) if D > 3 else xyz).reshape(B * P, D)
+        h = linear_rows(x, *folded(enc.conv1, enc.bn1), relu=True)           # (M,64)
+        trans_feat = None
+        if enc.feature_transform:
+            trans_feat = enc.fstn.forward_rows(h, P)                         # (B,64,64)
+            h = torch.bmm(h.view(B, P, -1), trans_feat).reshape(B * P, -1)
+        pointfeat = h
+        h = linear_rows(pointfeat, *folded(enc.conv2, enc.bn2), relu=True)
+        h = linear_rows(h, *folded(enc.conv3, enc.bn3), relu=False)
+        g = h.view(B, P, -1).max(dim=1)[0]                                   # (B,1024)
+        # head conv1 on cat([global (1024, per proposal), pointfeat (64, per point)]) + bn1
+        W, b = folded(self.conv1, self.bn1)
+        c = self.__dict__.get('_head_split')
+        if c is None or c[0] is not W:                       # per-point / per-proposal column halves
+            c = (W, W[:, 1024:].contiguous(), W[:, :1024].contiguous(), torch.zeros_like(b))
+            self.__dict__['_head_split'] = c
+        y = linear_rows(pointfeat, c[1], c[3], relu=True, gbias=F.linear(g, c[2], b).contiguous(),
+                        rows_per_group=P)
+        y = linear_rows(y, *folded(self.conv2, self.bn2), relu=True)
+        y = linear_rows(y, *folded(self.conv3, self.bn3), relu=True)
+        y = F.linear(y, self.conv4.weight[:, :, 0], self.conv4.bias)
+        return F.log_softmax(y, dim=-1).view(B, P, self.k), trans_feat
 
     def _forward_factored(self, x):
         """Inference path: the 1024 global-feature channels of the 1088-channel

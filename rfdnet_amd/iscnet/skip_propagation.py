@@ -37,11 +37,10 @@ class SkipPropagation(nn.Module):
         xyz, features = self._break_up_pc(input_point_cloud)
         # the instance-label channel is all zeros at generation time (:52-53)
         features = torch.cat([features, torch.zeros_like(features)], dim=1)
-        xyz, features = self.stn(xyz, features, box_xyz, box_orientations)
-        B, _, K, P = features.size()
-        inp = torch.cat([xyz, features[:, 0].unsqueeze(1)], dim=1)          # (B, 3+f, K, P)
-        inp = inp.permute(0, 2, 3, 1).contiguous().view(B * K, P, -1)
-        seg_pred, _ = self.point_seg(inp.transpose(1, 2).contiguous())
+        rows, gfeat = self.stn.forward_rows(xyz, features, box_xyz, box_orientations)   # (B*K,P,3), (B,C,K,P)
+        B, _, K, P = gfeat.size()
+        inp = torch.cat([rows, gfeat[:, 0].reshape(B * K, P, 1)], dim=2)                  # (B*K, P, 3+f)
+        seg_pred, _ = self.point_seg.forward_rows(inp)
         mask = torch.argmax(seg_pred.view(B * K * P, 2), dim=1).view(B * K, P, 1)
         # encoder input = cat([points, box feature repeated over the points]) * mask.
         # The 128 box-feature channels are one vector per proposal, so their share

@@ -151,6 +151,22 @@ class STN3d(nn.Module):
         return out.view(B, P, 3, -1).transpose(1, 2)
 
 
+def _stn3d_affine_rows(stn, rows):
+    """STN3d's regressor on row-major points: rows (B', P, 3) -> (B', 3, 4).  Eval-mode
+    BatchNorms folded into the layers; wide layers on the split-precision GEMM."""
+    from ..fold_bn import folded, linear_rows
+    Bp, P, _ = rows.shape
+    h = linear_rows(rows.reshape(Bp * P, 3), *folded(stn.conv1, stn.bn1), relu=True)
+    h = linear_rows(h, *folded(stn.conv2, stn.bn2), relu=True)
+    h = linear_rows(h, *folded(stn.conv3, stn.bn3), relu=True)
+    g = h.view(Bp, P, -1).max(dim=1)[0]
+    g = linear_rows(g, *folded(stn.fc1, stn.bn4), relu=True)
+    g = linear_rows(g, *folded(stn.fc2, stn.bn5), relu=True)
+    g = F.linear(g, stn.fc3.weight, stn.fc3.bias)
+    g = g + torch.eye(3, 4, device=g.device, dtype=g.dtype).view(1, 12)
+    return g.view(Bp, 3, 4)
+
+
 class STN_Group(nn.Module):
     """Group scan points around box centres, rotate them into the box frame
     (-heading about z) and apply the learned STN3d affine."""
@@ -167,6 +183,26 @@ class STN_Group(nn.Module):
             radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True, normalize_xyz=normalize_xyz,
             sample_uniformly=sample_uniformly, ret_unique_cnt=ret_unique_cnt)
         self.stn3d = STN3d(num_points=nsample)
+
+    def forward_rows(self, xyz, features=None, new_xyz=None, orientations=None):
+        """Inference path that stays ROW-major: -> (points (B*K, P, 3) in the box
+        frame after the learned affine, grouped_features (B,C,K,P)).  Same values as
+        forward(), without the transposes around every stage."""
+        grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
+        B, K = orientations.size()
+        P = grouped_xyz.shape[3]
+        rows = grouped_xyz.permute(0, 2, 3, 1).reshape(B * K, P, 3)
+        cos, sin = torch.cos(orientations).view(-1), torch.sin(orientations).view(-1)
+        rot_t = torch.zeros(B * K, 3, 3, device=rows.device, dtype=rows.dtype)   # transpose of the rotation
+        rot_t[:, 0, 0] = cos
+        rot_t[:, 1, 0] = sin
+        rot_t[:, 0, 1] = -sin
+        rot_t[:, 1, 1] = cos
+        rot_t[:, 2, 2] = 1.
+        rows = torch.bmm(rows, rot_t)
+        A = _stn3d_affine_rows(self.stn3d, rows)
+        rows = torch.bmm(rows, A[:, :, :3].transpose(1, 2)) + A[:, :, 3].unsqueeze(1)
+        return rows, grouped_features
 
     def forward(self, xyz, features=None, new_xyz=None, orientations=None):
         grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
