@@ -131,10 +131,10 @@ class MeshSink(object):
 
     def push(self, v, f):
         """Queue the meshes of the scene just finished; the copy is STARTED by
-        start_pending() once the next scene is past its backbone (the
-        multi-workgroup FPS exchanges 8-byte granules through memory every round
-        and runs 70 % slower with a PCIe copy in flight; the MFMA-bound decoder
-        does not care)."""
+        start_pending() when the next scene launches its last (longest) decode:
+        small kernels run 3-10x slower with a PCIe copy in flight (the
+        multi-workgroup FPS, which exchanges 8-byte granules through memory every
+        round, 70 % slower); the MFMA-bound decoder does not care."""
         self.pending = (v, f)
 
     def start_pending(self):
@@ -168,14 +168,15 @@ class MeshSink(object):
 
 def run_scene(net, pc, sink):
     """ISCNet.generate(selection='all') stage by stage (network.py), with the
-    previous scene's mesh copy released after the backbone."""
+    previous scene's mesh copy released behind the last decode launch."""
     with torch.no_grad():
         end_points, proposal_features = net.detect(pc)
-        sink.start_pending()
         ids = net.select_proposals(end_points, 'all', pc)
         codes = net.object_codes(end_points, proposal_features, ids, pc)
         cls = net.cls_codes(end_points, ids)
         gen = net.completion.generator
+        # the previous scene's PCIe copy rides behind the last (longest) decode launch
+        gen.round_hook = lambda r, depth: sink.start_pending() if r == depth else None
         meshes = gen.generate_mesh(codes, cls)
     v, f, _, _ = gen.last_buffers                              # all K meshes: one vertex / one face buffer
     sink.push(v, f)

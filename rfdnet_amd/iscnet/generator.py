@@ -43,6 +43,7 @@ class Generator3D(object):
             # libsimplify are out of scope
             raise NotImplementedError("refinement / normals / simplification are not on the hot path")
         self.model = model
+        self.round_hook = None
         self.points_batch_size = points_batch_size      # kept for signature parity; no chunking needed
         self.refinement_step = refinement_step
         self.threshold = threshold
@@ -135,6 +136,8 @@ class Generator3D(object):
             lin = torch.full((n_tiles * TILE,), -1, dtype=torch.int32, device=dev)
             _call("rfd_mise_collect", dev, K, res0, depth, pstate.data_ptr(), offsets.data_ptr(),
                   cursors.data_ptr(), float(box_size), pts.data_ptr(), lin.data_ptr())
+            if self.round_hook is not None:           # e.g. release a host copy behind the long decode
+                self.round_hook(rounds, depth)
             logits = dec.decode_tiles(pts, tile_prop, table, fc_p_w)
             _call("rfd_mise_scatter", dev, n_tiles, res0, depth, tile_prop.data_ptr(), lin.data_ptr(),
                   logits.data_ptr(), values.data_ptr(), pstate.data_ptr())

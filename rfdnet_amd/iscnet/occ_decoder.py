@@ -121,11 +121,19 @@ class DecoderCBatchNorm(nn.Module):
     def fold(self, z, c):
         """Per-proposal table (K,23,256) + scaled fc_p weight for codes z, c."""
         _, kw0, kw1 = self.packed_weights()
-        sd = {k: v.detach() for k, v in self.state_dict().items()}
-        if self.z_dim == 0:
-            sd["fc_z.weight"] = torch.zeros(256, 0, device=c.device)
-            sd["fc_z.bias"] = torch.zeros(256, device=c.device)
-        return occ_fold.fold_table(sd, z, c, kw0, kw1)
+        if self.training:                  # parameters may move under us: fold from the live tensors
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            if self.z_dim == 0:
+                sd["fc_z.weight"] = torch.zeros(256, 0, device=c.device)
+                sd["fc_z.bias"] = torch.zeros(256, device=c.device)
+            return occ_fold.fold_table(sd, z, c, kw0, kw1)
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if getattr(self, "_fold_key", None) != key:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._fold_consts = occ_fold.stacked_constants(sd, kw0, kw1)
+            self._fold_key = key
+        return occ_fold.fold_table_stacked(self._fold_consts, z, c)
 
     def decode_tiles(self, pts, tile_prop, table, fc_p_w, mode=None, tile_src=None):
         """pts (n_src_tiles*128,3) f32, tile_prop (n_tiles,) i32 [, tile_src

@@ -93,6 +93,68 @@ def fold_table(sd, z, c, kw0, kw1, prefix=""):
     return table, fc_p_w
 
 
+def stacked_constants(sd, kw0, kw1, prefix=""):
+    """Everything of fold_table() that does not depend on the codes, stacked over
+    the 11 CBN layers (order: blocks.i.bn_0, blocks.i.bn_1 for i<5, then bn) so
+    that the per-scene fold is ONE (K,C)x(C,22*256) GEMM and a handful of
+    elementwise kernels instead of 22 single-tile GEMMs and ~150 tiny launches."""
+    def g(k):
+        return sd[prefix + k]
+
+    names = []
+    for i in range(N_BLOCKS):
+        names += ["blocks.%d.bn_0" % i, "blocks.%d.bn_1" % i]
+    names.append("bn")
+    KH = KA + kw1
+    wg = [g(n + ".conv_gamma.weight").reshape(HIDDEN, -1) for n in names]
+    wb = [g(n + ".conv_beta.weight").reshape(HIDDEN, -1) for n in names]
+    bg = [g(n + ".conv_gamma.bias") for n in names]
+    bb = [g(n + ".conv_beta.bias") for n in names]
+    dev, dt = wg[0].device, wg[0].dtype
+    extra, smul, tmul = [], [], []
+    cumb = torch.zeros(HIDDEN, device=dev, dtype=dt)
+    for i in range(N_BLOCKS):
+        extra += [cumb, g("blocks.%d.fc_0.bias" % i)]
+        smul += [2.0 ** (KA - KH), 2.0 ** (-kw0[i])]
+        tmul += [2.0 ** KA, 2.0 ** KA]
+        cumb = cumb + g("blocks.%d.fc_1.bias" % i)
+    extra.append(cumb)
+    smul.append(2.0 ** (-KH))
+    tmul.append(1.0)
+    return {
+        "w": torch.cat(wg + wb, dim=0).contiguous(),               # (22*256, C)
+        "b": torch.cat(bg + bb, dim=0).contiguous(),
+        "sqrtv": torch.stack([torch.sqrt(g(n + ".bn.running_var") + BN_EPS) for n in names]),
+        "mean": torch.stack([g(n + ".bn.running_mean") for n in names]),
+        "extra": torch.stack(extra),
+        "smul": torch.tensor(smul, device=dev, dtype=dt).view(1, -1, 1),
+        "tmul": torch.tensor(tmul, device=dev, dtype=dt).view(1, -1, 1),
+        "fc_p_b": g("fc_p.bias"),
+        "fc_p_w": (g("fc_p.weight").reshape(HIDDEN, 3) * (2.0 ** KH)).contiguous(),
+        "fc_z_w": g("fc_z.weight") if (prefix + "fc_z.weight") in sd else None,
+        "fc_z_b": g("fc_z.bias") if (prefix + "fc_z.bias") in sd else None,
+        "row0_mul": 2.0 ** KH,
+    }
+
+
+def fold_table_stacked(k, z, c):
+    """fold_table() on the stacked constants: same per-element arithmetic (only the
+    GEMM summation order differs).  Returns (table (K,23,256), fc_p_w_scaled)."""
+    K = c.shape[0]
+    L = k["mean"].shape[0]
+    gb = torch.addmm(k["b"], c, k["w"].t()).view(K, 2 * L, HIDDEN)
+    scale = gb[:, :L] / k["sqrtv"]
+    shift = gb[:, L:] - k["mean"] * scale
+    table = torch.empty(K, TABLE_ROWS, HIDDEN, device=c.device, dtype=c.dtype)
+    if k["fc_z_w"] is not None and z.shape[1] > 0:
+        table[:, 0] = (k["fc_p_b"][None, :] + torch.addmm(k["fc_z_b"], z, k["fc_z_w"].t())) * k["row0_mul"]
+    else:
+        table[:, 0] = (k["fc_p_b"] * k["row0_mul"])[None, :]
+    table[:, 1::2] = scale * k["smul"]
+    table[:, 2::2] = (shift + scale * k["extra"]) * k["tmul"]
+    return table, k["fc_p_w"]
+
+
 def stacked_fc_weights(sd, prefix=""):
     """(5,256,256) fc_0 and fc_1 weight stacks (Conv1d kernels squeezed)."""
     fc0 = torch.stack([sd[prefix + "blocks.%d.fc_0.weight" % i].reshape(HIDDEN, HIDDEN)

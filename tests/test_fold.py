@@ -96,3 +96,18 @@ def test_choose_kw_keeps_f16_headroom():
     kw = occ_fold.choose_kw([w])
     assert float(w.abs().max()) * 2.0 ** kw <= 16384.0 < float(w.abs().max()) * 2.0 ** (kw + 1)
     assert occ_fold.choose_kw([torch.zeros(2, 2)]) == 0
+
+
+def test_stacked_fold_equals_layerwise_fold(golden_dir):
+    """The per-scene fast path (one GEMM over all 11 CBN layers) produces the same
+    table as the layer-by-layer definition."""
+    fx, sd = _setup(golden_dir)
+    fc0, fc1 = occ_fold.stacked_fc_weights(sd)
+    kw0 = [occ_fold.choose_kw([fc0[i]]) for i in range(5)]
+    kw1 = occ_fold.choose_kw([fc1])
+    z, c = torch.from_numpy(fx["z"]), torch.from_numpy(fx["c"])
+    t_ref, w_ref = occ_fold.fold_table(sd, z, c, kw0, kw1)
+    t, w = occ_fold.fold_table_stacked(occ_fold.stacked_constants(sd, kw0, kw1), z, c)
+    assert torch.equal(w, w_ref)
+    # identical arithmetic per element; only the GEMM summation order may differ
+    assert torch.allclose(t, t_ref, rtol=1e-5, atol=1e-5 * float(t_ref.abs().max()))
