@@ -23,6 +23,7 @@
 // Operands are pre-scaled by 2^sa / 2^sw (exact) to keep the lo parts in the
 // normal f16 range; the epilogue multiplies by 2^-(sa+sw).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -198,9 +199,303 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
     }
 }
 
+
+// ======================================================================================
+// Row-owner kernel for the big shapes (M % 256 == 0, N % 256 == 0, K % 128 == 0).
+//
+// The 128 x 128 kernel above re-reads 32 KiB of operands per 3 MFLOP issued and
+// both operands pass through LDS; at the encoder's shapes it is bound by the
+// L2 -> CU traffic, not by the matrix pipe.  Here a workgroup owns a 256 x 256
+// output tile and each WAVE 64 rows x 256 columns = 2 x 8 accumulator blocks (256
+// accumulator registers per lane):
+//   * activations never touch LDS: lane (n, h) loads 16 consecutive k of ITS rows
+//     (one contiguous 64-byte chunk per row and 32-wide k piece), rectifies / scales /
+//     splits them in registers and uses them directly as B fragments -- the k order
+//     inside a piece is whatever that makes it (the packed W uses the same order);
+//   * W streams through a 4-slot LDS ring of 32-KiB pieces (LDS-DMA, three pieces
+//     ahead), one fragment pair feeding 6 MFMAs (two row groups).
+// Per 32-wide k piece a CU moves 64 KiB (32 KiB x fp32, 32 KiB W) for 12.6 MFLOP issued.
+constexpr int RM = 256, RN = 256, RK = 32;
+constexpr int R_PIECE_BYTES = 32 * 1024;
+
+// layout 2: [N/256][K/32][kstep 2][blk 8][split 2][lane 64][8] f16,
+// n = 256 ntile + 32 blk + (lane & 31), k = 32 piece + 16 (lane >> 5) + 8 kstep + j
+__global__ void gemm_pack_rows_kernel(int N, int K, int sw, const float *__restrict__ W,
+                                      _Float16 *__restrict__ packed) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * K * 2;
+  if (e >= total) return;
+  const int j = e & 7;
+  const int lane = (e >> 3) & 63;
+  const int split = (e >> 9) & 1;
+  const int blk = (e >> 10) & 7;
+  const int kstep = (e >> 13) & 1;
+  const size_t rest = e >> 14;
+  const int piece = (int)(rest % (K / RK));
+  const int ntile = (int)(rest / (K / RK));
+  const int n = ntile * RN + blk * 32 + (lane & 31);
+  const int k = piece * RK + 16 * (lane >> 5) + 8 * kstep + j;
+  const float w = ldexpf(W[(size_t)n * K + k], sw);
+  const _Float16 hi = (_Float16)w;
+  const _Float16 lo = (_Float16)(w - (float)hi);
+  packed[e] = split == 0 ? hi : lo;
+}
+
+#ifdef RFD_GEMM_TRACE
+// debug build only (tools/gemm_trace.py): wave 0 / lane 0 of the first workgroups
+// overwrite C with s_memtime stamps
+#define GSTAMP(st_, slot)                                                           \
+  do {                                                                               \
+    if ((st_).trace && (slot) < 126) (st_).trace[(slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define GSTAMP(st_, slot) do { } while (0)
+#endif
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool RELU_IN>
+struct RowsState {
+  f32x16 acc[2][8];
+  f32x4 xr[2][2][4];        // [piece & 1][row group][16 consecutive k of this lane]
+  half8 bh[2], bl[2];       // B fragments of the current k-step, per row group
+  unsigned nh[2][4], nl[2][4];
+  const float *xp[2];       // this lane's two rows, at the NEXT piece to load
+  const char *wp;           // packed W of this n tile (wave-uniform)
+  unsigned char *ring;
+  float a_scale;
+  int wave, lane;
+  unsigned lane16;
+  unsigned long long *trace;
+  int tslot;
+
+  __device__ __forceinline__ void load_x(int slot) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                   "global_load_dwordx4 %1, %4, off offset:16\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:32\n\t"
+                   "global_load_dwordx4 %3, %4, off offset:48"
+                   : "=&v"(xr[slot][g][0]), "=&v"(xr[slot][g][1]), "=&v"(xr[slot][g][2]), "=&v"(xr[slot][g][3])
+                   : "v"(xp[g])
+                   : "memory");
+  }
+  // One 1-KiB transfer of the piece at byte offset `poff` of this n tile's stream.  The
+  // instruction's immediate offset moves the global AND the LDS address, so a step needs
+  // two address pairs (jj < 4, jj >= 4) instead of eight.
+  template <int JJ>
+  __device__ __forceinline__ void dma1(unsigned poff, int slot) {
+    const char *src = wp + poff + (wave * 8 + JJ) * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane16),
+                                     (lds_void *)(ring + slot * R_PIECE_BYTES + (wave * 8 + JJ) * 1024), 16,
+                                     0, 0);
+  }
+  // jj is a constant after unrolling: the switch folds to the one instruction
+  __device__ __forceinline__ void dma_jj(unsigned poff, int slot, int jj) {
+    switch (jj) {
+      case 0: dma1<0>(poff, slot); break;
+      case 1: dma1<1>(poff, slot); break;
+      case 2: dma1<2>(poff, slot); break;
+      case 3: dma1<3>(poff, slot); break;
+      case 4: dma1<4>(poff, slot); break;
+      case 5: dma1<5>(poff, slot); break;
+      case 6: dma1<6>(poff, slot); break;
+      default: dma1<7>(poff, slot); break;
+    }
+  }
+  // two of the 8 inputs of (slot, k-step s, row group g) -> word i of the next B pair
+  __device__ __forceinline__ void conv_slice(int slot, int s, int g, int i) {
+    const f32x4 v = xr[slot][g][2 * s + (i >> 1)];
+    float a0 = v[2 * (i & 1)] * a_scale, a1 = v[2 * (i & 1) + 1] * a_scale;
+    if (RELU_IN) {
+      a0 = a0 > 0.f ? a0 : 0.f;
+      a1 = a1 > 0.f ? a1 : 0.f;
+    }
+    const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+    const float r0 = a0 - (float)h2[0], r1 = a1 - (float)h2[1];
+    nh[g][i] = __builtin_bit_cast(unsigned, h2);
+    nl[g][i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+  }
+  __device__ __forceinline__ void conv_finish() {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      bh[g] = __builtin_bit_cast(half8, u32x4{nh[g][0], nh[g][1], nh[g][2], nh[g][3]});
+      bl[g] = __builtin_bit_cast(half8, u32x4{nl[g][0], nl[g][1], nl[g][2], nl[g][3]});
+    }
+  }
+
+  // one 32-wide k piece P (ring slot P & 3, x slot P & 1); `dpiece` = piece whose W is
+  // fetched now; x of piece P+2 is fetched half-way (load_next: that piece exists)
+  template <int PS>
+  __device__ __forceinline__ void step(unsigned dpiece, bool load_next) {
+    constexpr int XS = PS & 1;
+    GSTAMP(*this, tslot);
+    const half8 *w = reinterpret_cast<const half8 *>(ring + PS * R_PIECE_BYTES) + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8 f0 = w[(s * 16) * 64], f1 = w[(s * 16 + 1) * 64];
+      const half8 h0 = bh[0], l0 = bl[0], h1 = bh[1], l1 = bl[1];
+#pragma unroll
+      for (int blk = 0; blk < 8; ++blk) {
+        const half8 ch = f0, cl = f1;
+        if (blk < 7) {
+          f0 = w[(s * 16 + 2 * blk + 2) * 64];
+          f1 = w[(s * 16 + 2 * blk + 3) * 64];
+        }
+        acc[0][blk] = mfma(ch, h0, acc[0][blk]);
+        acc[1][blk] = mfma(ch, h1, acc[1][blk]);
+        acc[0][blk] = mfma(ch, l0, acc[0][blk]);
+        acc[1][blk] = mfma(ch, l1, acc[1][blk]);
+        acc[0][blk] = mfma(cl, h0, acc[0][blk]);
+        acc[1][blk] = mfma(cl, h1, acc[1][blk]);
+        // the next k-step's B pairs: k-step 1 of this piece, or k-step 0 of the next
+        conv_slice(s == 0 ? XS : (XS ^ 1), s ^ 1, blk >> 2, blk & 3);
+        if (blk & 1) dma_jj(dpiece, (PS + 3) & 3, 4 * s + (blk >> 1));
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (blk & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      conv_finish();
+      GSTAMP(*this, tslot + 1 + 2 * s);
+      if (s == 0) {
+        // everything but the last eight W transfers has landed: the x of piece P+1
+        // (issued one piece ago, converted next) and the ring pieces of the next steps.
+        // This piece's x slot is dead now: fetch piece P+2 into it.
+        wait_vm<8>();
+        GSTAMP(*this, tslot + 2);
+        // (never issue a load whose result is not consumed: the compiler treats the
+        // asm's outputs as written at once and would reuse dead registers while the
+        // data is still in flight)
+        if (load_next) {
+          load_x(XS);
+          xp[0] += RK;
+          xp[1] += RK;
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    tslot += 4;
+  }
+};
+
+template <bool RELU_IN>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * R_PIECE_BYTES];
+  const int t = threadIdx.x;
+  RowsState<RELU_IN> st;
+  st.lane = t & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  st.lane16 = (unsigned)st.lane * 16u;
+  st.ring = smem;
+  st.a_scale = g.a_scale;
+  const int half = st.lane >> 5, n = st.lane & 31;
+  const int ntiles = g.N / RN;
+  const int ntile = blockIdx.x % ntiles, mtile = blockIdx.x / ntiles;   // n tiles of one row tile back to back
+  const int m0 = mtile * RM + st.wave * 64, n0 = ntile * RN;
+  const int np = g.K / RK;
+  st.wp = reinterpret_cast<const char *>(g.Wp) + ((size_t)g.N * g.K * 2 + (size_t)ntile * np * (R_PIECE_BYTES / 2)) * 2;
+  st.xp[0] = g.A + (size_t)(m0 + n) * g.lda + 16 * half;
+  st.xp[1] = g.A + (size_t)(m0 + 32 + n) * g.lda + 16 * half;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) st.acc[i][b] = f32x16{0.f};
+
+  st.trace = nullptr;
+  st.tslot = 2;
+#ifdef RFD_GEMM_TRACE
+  if (st.wave == 0 && st.lane == 0 && blockIdx.x < 512 && (blockIdx.x & 7) == 0)
+    st.trace = reinterpret_cast<unsigned long long *>(g.C) + (size_t)(blockIdx.x >> 3) * 128;
+  GSTAMP(st, 0);
+#endif
+  // prologue: x of pieces 0 and 1, W pieces 0..2
+  st.load_x(0);
+  st.xp[0] += RK;
+  st.xp[1] += RK;
+  st.load_x(1);
+  st.xp[0] += RK;
+  st.xp[1] += RK;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) st.dma_jj(p * R_PIECE_BYTES, p, jj);
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) st.conv_slice(0, 0, i >> 2, i & 3);
+  st.conv_finish();
+  GSTAMP(st, 1);
+
+  // x of piece p+2 is fetched in step p (if it exists);
+  // W of piece p+3 likewise (wraps to an already consumed piece at the end)
+  const unsigned wbytes = (unsigned)np * R_PIECE_BYTES;
+  unsigned doff = 3 * R_PIECE_BYTES;          // np >= 4
+  for (int p4 = 0; p4 < np; p4 += 4) {
+    st.template step<0>(doff, p4 + 2 < np);
+    doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
+    st.template step<1>(doff, p4 + 3 < np);
+    doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
+    st.template step<2>(doff, p4 + 4 < np);
+    doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
+    st.template step<3>(doff, p4 + 5 < np);
+    doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
+  }
+  wait_vm<0>();
+#ifdef RFD_GEMM_TRACE
+  GSTAMP(st, 126 > st.tslot ? st.tslot : 125);
+  if (blockIdx.x < 512) return;
+#endif
+
+  // ---- epilogue: scale back, add bias / group bias / residual, ReLU; lane (n, half)
+  // holds channels 32 blk + 8 q + 4 half + (0..3) of its two rows: 16-byte accesses
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + 32 * i + n;
+    float *crow = g.C + (size_t)m * g.ldc + n0 + 4 * half;
+    const float *rrow = g.R ? g.R + (size_t)m * g.ldr + n0 + 4 * half : nullptr;
+    const float *grow = g.gbias ? g.gbias + (size_t)(m / g.rows_per_group) * g.N + n0 + 4 * half : nullptr;
+    const float *brow = g.bias ? g.bias + n0 + 4 * half : nullptr;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * b + 8 * q;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = st.acc[i][b][4 * q + e] * g.out_scale;
+        if (brow) v += *reinterpret_cast<const f32x4 *>(brow + c);
+        if (grow) v += *reinterpret_cast<const f32x4 *>(grow + c);
+        if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + c);
+        if (g.relu_out) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(crow + c) = v;
+      }
+    }
+  }
+  (void)status;
+}
+
 }  // namespace
 
-RFD_API size_t rfd_gemm_packed_bytes(int N, int K) { return (size_t)N * K * 2 * sizeof(_Float16); }
+// two layouts: the 128 x 128 tile stream, then (for N % 256 == 0, K % 128 == 0) the row-owner stream
+RFD_API size_t rfd_gemm_packed_bytes(int N, int K) { return (size_t)N * K * 2 * sizeof(_Float16) * 2; }
 
 // W [N][K] fp32 (device) -> packed (device).  N % 128 == 0, K % 32 == 0.
 RFD_API int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, void *stream) {
@@ -209,6 +504,11 @@ RFD_API int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, 
   hipLaunchKernelGGL(gemm_pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, N, K, sw, W, (_Float16 *)packed);
   RFD_CHECK_LAUNCH();
+  if (N % RN == 0 && K % 128 == 0) {
+    hipLaunchKernelGGL(gemm_pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, N, K, sw, W, (_Float16 *)packed + total);
+    RFD_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -229,7 +529,19 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
   g.gbias = gbias; g.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; g.R = R; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.relu_in = relu_in; g.relu_out = relu_out;
   g.a_scale = ldexpf(1.f, sa); g.out_scale = ldexpf(1.f, -(sa + sw));
-  hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, (hipStream_t)stream, g);
+  const bool aligned = !(ldc & 3) && !(ldr & 3) && !((uintptr_t)C & 15) && !((uintptr_t)R & 15) &&
+                       !((uintptr_t)bias & 15) && !((uintptr_t)gbias & 15);
+  if (M % RM == 0 && N % RN == 0 && K % 128 == 0 && aligned && getenv("RFD_GEMM_TILE_ONLY") == nullptr) {
+    RfdWorkspace *ws;
+    int rc = rfd_get_workspace(&ws);
+    if (rc) return rc;
+    if (relu_in)
+      hipLaunchKernelGGL(gemm_rows_kernel<true>, dim3((M / RM) * (N / RN)), dim3(256), 0, (hipStream_t)stream, g, ws->status);
+    else
+      hipLaunchKernelGGL(gemm_rows_kernel<false>, dim3((M / RM) * (N / RN)), dim3(256), 0, (hipStream_t)stream, g, ws->status);
+  } else {
+    hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, (hipStream_t)stream, g);
+  }
   RFD_CHECK_LAUNCH();
   return 0;
 }

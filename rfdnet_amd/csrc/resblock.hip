@@ -163,12 +163,14 @@ struct Tile {
 
   // wave-uniform source address (scalar base, re-derived every tile so that the 8 x NP
   // constant offsets are not hoisted into -- and spilled from -- vector registers)
-  __device__ __forceinline__ void dma(int piece, int slot) {
+  __device__ __forceinline__ void dma1(int piece, int slot, int jj) {
     const char *src = reinterpret_cast<const char *>(packed) + ((size_t)piece * PIECE_FRAGS + wave * 8) * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(src + jj * 1024 + lane16),
+                                     (lds_void *)(s_ring + slot * PIECE_BYTES + (wave * 8 + jj) * 1024), 16, 0, 0);
+  }
+  __device__ __forceinline__ void dma(int piece, int slot) {
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj)
-      __builtin_amdgcn_global_load_lds((gbl_void *)(src + jj * 1024 + lane16),
-                                       (lds_void *)(s_ring + slot * PIECE_BYTES + (wave * 8 + jj) * 1024), 16, 0, 0);
+    for (int jj = 0; jj < 8; ++jj) dma1(piece, slot, jj);
   }
 
   // 8 inputs of one k-step.  Issued as opaque instructions: the compiler's own wait
@@ -238,7 +240,8 @@ struct Tile {
       constexpr int k = (I + XD) % NP;
       load_x<k % XS, 64 * (k % KS)>(xn);
     }
-    dma((I + 3) % NP, (I + 3) & 3);
+    // (its eight 1-KiB transfers are issued one by one between the MFMAs below: a
+    // transfer costs the issuing wave ~60-100 cycles that an MFMA in flight hides)
     __builtin_amdgcn_sched_barrier(0);
     if (I < KS) {
       // ---- first GEMM, k-step I: [h ; shortcut] += [W0 ; Ws][:, 16I..16I+15] relu(x).
@@ -257,11 +260,13 @@ struct Tile {
         acc[ob] = mfma(cl, bh, acc[ob]);
         if (ob < 4 && I + 1 < KS) conv_slice((I + 1) % XS, ob);
         if (ob >= 4 && ob < 12 && I == KS - 1) epi_slice(acc[0], 4 * half, ob - 4);
+        if (ob & 1) dma1((I + 3) % NP, (I + 3) & 3, ob >> 1);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        if (ob & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -294,12 +299,14 @@ struct Tile {
         c = mfma(c3, b.hi1, c);
         acc[8 + ob] = c;
         if (mb < 7) epi_slice(acc[(mb + 1) & 7], 32 * (mb + 1) + 4 * half, ob);
+        dma1((I + 3) % NP, (I + 3) & 3, ob);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (q == 2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -416,6 +423,11 @@ __global__ __launch_bounds__(256) void resblock_kernel(
     run_steps<K_IN>(tl, std::make_integer_sequence<int, T::NP>{});
   }
   wait_vmcnt<0>();
+  // the last tile's "next tile" prefetch is never consumed: keep its destination
+  // registers reserved until the data has landed (the compiler sees the opaque loads
+  // as complete at issue and would otherwise reuse the registers under them)
+#pragma unroll
+  for (int k = 0; k < XS; ++k) asm volatile("" ::"v"(tl.xr[k][0]), "v"(tl.xr[k][1]));
   if ((tl.amax16 & 0xffffu) >= 0x7bffu || (tl.amax16 >> 16) >= 0x7bffu) atomicOr(status, 2u);
 }
 
