@@ -336,39 +336,57 @@ struct RowsState {
     const half8 *w = reinterpret_cast<const half8 *>(ring + PS * R_PIECE_BYTES) + lane;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      half8 f0 = w[(s * 16) * 64], f1 = w[(s * 16 + 1) * 64];
+      // two column blocks x two row groups = FOUR independent accumulators in rotation
+      // (a dependent MFMA issued with only one other MFMA in between still waits for its
+      // producer); the next pair's fragments are read in the shadow
+      half8 c[2][2], nx[2][2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        c[o][0] = w[(s * 16 + 2 * o) * 64];
+        c[o][1] = w[(s * 16 + 2 * o + 1) * 64];
+      }
       const half8 h0 = bh[0], l0 = bl[0], h1 = bh[1], l1 = bl[1];
 #pragma unroll
-      for (int blk = 0; blk < 8; ++blk) {
-        const half8 ch = f0, cl = f1;
-        if (blk < 7) {
-          f0 = w[(s * 16 + 2 * blk + 2) * 64];
-          f1 = w[(s * 16 + 2 * blk + 3) * 64];
+      for (int bp = 0; bp < 4; ++bp) {
+        if (bp < 3) {
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            nx[o][0] = w[(s * 16 + 4 * bp + 4 + 2 * o) * 64];
+            nx[o][1] = w[(s * 16 + 4 * bp + 5 + 2 * o) * 64];
+          }
         }
-        acc[0][blk] = mfma(ch, h0, acc[0][blk]);
-        acc[1][blk] = mfma(ch, h1, acc[1][blk]);
-        acc[0][blk] = mfma(ch, l0, acc[0][blk]);
-        acc[1][blk] = mfma(ch, l1, acc[1][blk]);
-        acc[0][blk] = mfma(cl, h0, acc[0][blk]);
-        acc[1][blk] = mfma(cl, h1, acc[1][blk]);
+        const int b0 = 2 * bp, b1 = 2 * bp + 1;
+        acc[0][b0] = mfma(c[0][0], h0, acc[0][b0]);
+        acc[1][b0] = mfma(c[0][0], h1, acc[1][b0]);
+        acc[0][b1] = mfma(c[1][0], h0, acc[0][b1]);
+        acc[1][b1] = mfma(c[1][0], h1, acc[1][b1]);
+        acc[0][b0] = mfma(c[0][0], l0, acc[0][b0]);
+        acc[1][b0] = mfma(c[0][0], l1, acc[1][b0]);
+        acc[0][b1] = mfma(c[1][0], l0, acc[0][b1]);
+        acc[1][b1] = mfma(c[1][0], l1, acc[1][b1]);
+        acc[0][b0] = mfma(c[0][1], h0, acc[0][b0]);
+        acc[1][b0] = mfma(c[0][1], h1, acc[1][b0]);
+        acc[0][b1] = mfma(c[1][1], h0, acc[0][b1]);
+        acc[1][b1] = mfma(c[1][1], h1, acc[1][b1]);
         // the next k-step's B pairs: k-step 1 of this piece, or k-step 0 of the next
-        conv_slice(s == 0 ? XS : (XS ^ 1), s ^ 1, blk >> 2, blk & 3);
-        if (blk & 1) dma_jj(dpiece, (PS + 3) & 3, 4 * s + (blk >> 1));
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (blk & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        conv_slice(s == 0 ? XS : (XS ^ 1), s ^ 1, bp >> 1, 2 * (bp & 1));
+        conv_slice(s == 0 ? XS : (XS ^ 1), s ^ 1, bp >> 1, 2 * (bp & 1) + 1);
+        dma_jj(dpiece, (PS + 3) & 3, 4 * s + bp);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (q == 6) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (bp < 3) {
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            c[o][0] = nx[o][0];
+            c[o][1] = nx[o][1];
+          }
+        }
       }
       conv_finish();
       GSTAMP(*this, tslot + 1 + 2 * s);

@@ -227,49 +227,78 @@ struct Tile {
   template <int I>
   __device__ __forceinline__ void step() {
     const half8 *w = reinterpret_cast<const half8 *>(s_ring + (I & 3) * PIECE_BYTES) + lane;
-    // first fragments of this piece: their LDS latency hides behind the issue below
-    half8 f0 = w[0], f1 = w[64], f2, f3;
-    if (I >= KS) {
-      f2 = w[128];
-      f3 = w[192];
+    // Fragments of the first group of four output blocks: their LDS latency hides behind
+    // the issue below.  MFMA order everywhere: FOUR independent accumulators in rotation
+    // (a dependent MFMA that is not issued back to back with its producer waits ~45 extra
+    // cycles; with three or more other MFMAs in between it never waits).
+    half8 cur[4][2], nxt[4][2];
+    if (I < KS) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        cur[o][0] = w[(2 * o) * 64];
+        cur[o][1] = w[(2 * o + 1) * 64];
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        cur[o][0] = w[(4 * o) * 64];
+        cur[o][1] = w[(4 * o + 1) * 64];
+      }
     }
-    // ---- issue: x four k-steps ahead, then the ring piece three ahead
+    // ---- issue: x four k-steps ahead (the ring piece three ahead goes out one 1-KiB
+    // transfer at a time between the MFMAs below)
     if (I + XD < KS) {
       load_x<(I + XD) % XS, 64 * ((I + XD) % KS)>(xp);
     } else if (I >= NP - XD) {
       constexpr int k = (I + XD) % NP;
       load_x<k % XS, 64 * (k % KS)>(xn);
     }
-    // (its eight 1-KiB transfers are issued one by one between the MFMAs below: a
-    // transfer costs the issuing wave ~60-100 cycles that an MFMA in flight hides)
     __builtin_amdgcn_sched_barrier(0);
     if (I < KS) {
-      // ---- first GEMM, k-step I: [h ; shortcut] += [W0 ; Ws][:, 16I..16I+15] relu(x).
-      // Fragments are read one block ahead; the next k-step's B pair is converted in
-      // the shadow of the first blocks' MFMAs.
+      // ---- first GEMM, k-step I: [h ; shortcut] += [W0 ; Ws][:, 16I..16I+15] relu(x),
+      // four output blocks at a time; the next group's fragments and the next k-step's
+      // B pair are produced in the shadow of the 12 MFMAs
       const half8 bh = bhi, bl = blo;
 #pragma unroll
-      for (int ob = 0; ob < 16; ++ob) {
-        const half8 ch = f0, cl = f1;
-        if (ob < 15) {
-          f0 = w[(2 * ob + 2) * 64];
-          f1 = w[(2 * ob + 3) * 64];
+      for (int g = 0; g < 4; ++g) {
+        if (g < 3) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            nxt[o][0] = w[(2 * (4 * g + 4 + o)) * 64];
+            nxt[o][1] = w[(2 * (4 * g + 4 + o) + 1) * 64];
+          }
         }
-        acc[ob] = mfma(ch, bh, acc[ob]);
-        acc[ob] = mfma(ch, bl, acc[ob]);
-        acc[ob] = mfma(cl, bh, acc[ob]);
-        if (ob < 4 && I + 1 < KS) conv_slice((I + 1) % XS, ob);
-        if (ob >= 4 && ob < 12 && I == KS - 1) epi_slice(acc[0], 4 * half, ob - 4);
-        if (ob & 1) dma1((I + 3) % NP, (I + 3) & 3, ob >> 1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-        if (ob & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[4 * g + o] = mfma(cur[o][0], bh, acc[4 * g + o]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[4 * g + o] = mfma(cur[o][0], bl, acc[4 * g + o]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[4 * g + o] = mfma(cur[o][1], bh, acc[4 * g + o]);
+        if (g == 0 && I + 1 < KS) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) conv_slice((I + 1) % XS, i);
+        }
+        if ((g == 1 || g == 2) && I == KS - 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) epi_slice(acc[0], 4 * half, 4 * (g - 1) + i);
+        }
+        dma1((I + 3) % NP, (I + 3) & 3, 2 * g);
+        dma1((I + 3) % NP, (I + 3) & 3, 2 * g + 1);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (q < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (q == 5 || q == 10) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (g < 3) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            cur[o][0] = nxt[o][0];
+            cur[o][1] = nxt[o][1];
+          }
+        }
       }
       if (I + 1 < KS) {
         bhi = words_to_frag(nhw[0], nhw[1], nhw[2], nhw[3]);
@@ -277,39 +306,50 @@ struct Tile {
       }
       if (I == KS - 1) epi_finish();
     } else {
-      // ---- second GEMM, k-slab mb: out += W1[:, 32mb..32mb+31] relu(h[mb]); the
-      // next slab's relu(h) is converted in the shadow of these 48 MFMAs
+      // ---- second GEMM, k-slab mb: out += W1[:, 32mb..32mb+31] relu(h[mb]), four output
+      // blocks at a time in two halves (sub-step 0: fragments 4ob, 4ob+1; sub-step 1:
+      // 4ob+2, 4ob+3); the next slab's relu(h) is converted in the shadow of the MFMAs
       constexpr int mb = I - KS;
       const A2 b = a2;
 #pragma unroll
-      for (int ob = 0; ob < 8; ++ob) {
-        const half8 c0 = f0, c1 = f1, c2 = f2, c3 = f3;
-        if (ob < 7) {
-          f0 = w[(4 * ob + 4) * 64];
-          f1 = w[(4 * ob + 5) * 64];
-          f2 = w[(4 * ob + 6) * 64];
-          f3 = w[(4 * ob + 7) * 64];
-        }
-        f32x16 c = acc[8 + ob];
-        c = mfma(c0, b.hi0, c);
-        c = mfma(c0, b.lo0, c);
-        c = mfma(c1, b.hi0, c);
-        c = mfma(c2, b.hi1, c);
-        c = mfma(c2, b.lo1, c);
-        c = mfma(c3, b.hi1, c);
-        acc[8 + ob] = c;
-        if (mb < 7) epi_slice(acc[(mb + 1) & 7], 32 * (mb + 1) + 4 * half, ob);
-        dma1((I + 3) % NP, (I + 3) & 3, ob);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      for (int hg = 0; hg < 4; ++hg) {   // (group of 4 blocks, sub-step) = (hg >> 1, hg & 1)
+        const int g = hg >> 1, sub = hg & 1;
+        if (hg < 3) {
+          const int ng = (hg + 1) >> 1, nsub = (hg + 1) & 1;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+          for (int o = 0; o < 4; ++o) {
+            nxt[o][0] = w[(4 * (4 * ng + o) + 2 * nsub) * 64];
+            nxt[o][1] = w[(4 * (4 * ng + o) + 2 * nsub + 1) * 64];
+          }
+        }
+        const half8 bhq = sub ? b.hi1 : b.hi0, blq = sub ? b.lo1 : b.lo0;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[8 + 4 * g + o] = mfma(cur[o][0], bhq, acc[8 + 4 * g + o]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[8 + 4 * g + o] = mfma(cur[o][0], blq, acc[8 + 4 * g + o]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[8 + 4 * g + o] = mfma(cur[o][1], bhq, acc[8 + 4 * g + o]);
+        if (mb < 7) {
+          epi_slice(acc[(mb + 1) & 7], 32 * (mb + 1) + 4 * half, 2 * hg);
+          epi_slice(acc[(mb + 1) & 7], 32 * (mb + 1) + 4 * half, 2 * hg + 1);
+        }
+        dma1((I + 3) % NP, (I + 3) & 3, 2 * hg);
+        dma1((I + 3) % NP, (I + 3) & 3, 2 * hg + 1);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (q == 2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          if (q < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (q == 5 || q == 10) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (hg < 3) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            cur[o][0] = nxt[o][0];
+            cur[o][1] = nxt[o][1];
+          }
+        }
       }
       if (mb < 7) epi_finish();
     }
