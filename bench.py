@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--resolution0", type=int, default=32)
     ap.add_argument("--upsampling-steps", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="scenes reconstructed concurrently per GPU (one host thread + HIP stream + model "
                          "replica each); a step = one such batch")
     ap.add_argument("--mode", choices=["f16x3", "f16x1"], default="f16x3",
