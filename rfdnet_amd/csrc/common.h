@@ -33,9 +33,11 @@ void rfd_set_error(const char *where, hipError_t e);
 struct RfdWorkspace {
   unsigned long long *fps_slots;  // FPS_RING regions of FPS_REGION_GRANULES
   unsigned *status;               // device status word (0 = OK)
+  float *zeros;                   // RFD_ZEROS_FLOATS zeros (stand-in for absent bias vectors)
   std::atomic<unsigned> ring_pos;   // callers may come from several host threads / streams
   int num_cu;                     // multiprocessor count of the device
 };
+constexpr int RFD_ZEROS_FLOATS = 16384;
 constexpr int FPS_RING = 16;
 constexpr int FPS_MAX_WG = 256;                         // co-resident WGs/launch
 constexpr int FPS_REGION_GRANULES = FPS_MAX_WG * 2 * 5; // [wg][parity][field]

@@ -242,8 +242,8 @@ __global__ void gemm_pack_rows_kernel(int N, int K, int sw, const float *__restr
 }
 
 #ifdef RFD_GEMM_TRACE
-// debug build only (tools/gemm_trace.py): wave 0 / lane 0 of the first workgroups
-// overwrite C with s_memtime stamps
+// debug build only (tools/gemm_trace.py): wave 0 / lane 0 of some workgroups write
+// s_memtime stamps BEHIND the M rows of C (the tool allocates the extra rows)
 #define GSTAMP(st_, slot)                                                           \
   do {                                                                               \
     if ((st_).trace && (slot) < 126) (st_).trace[(slot)] = __builtin_amdgcn_s_memtime(); \
@@ -272,16 +272,24 @@ struct RowsState {
   unsigned long long *trace;
   int tslot;
 
+  // 16 bytes of row group g's next piece (q = 0..3).  Opaque to the compiler (its own wait
+  // insertion would drain vmcnt and the LDS-DMA pipeline with it); the explicit waits in
+  // step() cover these loads.
+  template <int Q>
+  __device__ __forceinline__ void load_x1(int slot, int g) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(xr[slot][g][Q]) : "v"(xp[g]), "n"(16 * Q) : "memory");
+  }
+  __device__ __forceinline__ void load_x_pair(int slot, int i) {   // loads 2i, 2i+1 of the 8
+    switch (i) {
+      case 0: load_x1<0>(slot, 0); load_x1<1>(slot, 0); break;
+      case 1: load_x1<2>(slot, 0); load_x1<3>(slot, 0); break;
+      case 2: load_x1<0>(slot, 1); load_x1<1>(slot, 1); break;
+      default: load_x1<2>(slot, 1); load_x1<3>(slot, 1); break;
+    }
+  }
   __device__ __forceinline__ void load_x(int slot) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-      asm volatile("global_load_dwordx4 %0, %4, off\n\t"
-                   "global_load_dwordx4 %1, %4, off offset:16\n\t"
-                   "global_load_dwordx4 %2, %4, off offset:32\n\t"
-                   "global_load_dwordx4 %3, %4, off offset:48"
-                   : "=&v"(xr[slot][g][0]), "=&v"(xr[slot][g][1]), "=&v"(xr[slot][g][2]), "=&v"(xr[slot][g][3])
-                   : "v"(xp[g])
-                   : "memory");
+    for (int i = 0; i < 4; ++i) load_x_pair(slot, i);
   }
   // One 1-KiB transfer of the piece at byte offset `poff` of this n tile's stream.  The
   // instruction's immediate offset moves the global AND the LDS address, so a step needs
@@ -371,6 +379,9 @@ struct RowsState {
         // the next k-step's B pairs: k-step 1 of this piece, or k-step 0 of the next
         conv_slice(s == 0 ? XS : (XS ^ 1), s ^ 1, bp >> 1, 2 * (bp & 1));
         conv_slice(s == 0 ? XS : (XS ^ 1), s ^ 1, bp >> 1, 2 * (bp & 1) + 1);
+        // x of piece P+2, two 16-byte loads per block pair of k-step 1 (this piece's x
+        // slot is dead after k-step 0), ahead of this iteration's W transfer
+        if (s == 1 && load_next) load_x_pair(XS, bp);
         dma_jj(dpiece, (PS + 3) & 3, 4 * s + bp);
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
@@ -391,27 +402,24 @@ struct RowsState {
       conv_finish();
       GSTAMP(*this, tslot + 1 + 2 * s);
       if (s == 0) {
-        // everything but the last eight W transfers has landed: the x of piece P+1
-        // (issued one piece ago, converted next) and the ring pieces of the next steps.
-        // This piece's x slot is dead now: fetch piece P+2 into it.
-        wait_vm<8>();
+        // everything but the last five W transfers has landed: the x of piece P+1
+        // (its last load went out before the last transfer of the previous step)
+        wait_vm<5>();
         GSTAMP(*this, tslot + 2);
-        // (never issue a load whose result is not consumed: the compiler treats the
-        // asm's outputs as written at once and would reuse dead registers while the
-        // data is still in flight)
-        if (load_next) {
-          load_x(XS);
-          xp[0] += RK;
-          xp[1] += RK;
-        }
       }
+    }
+    // (never issue a load whose result is not consumed: the compiler treats the asm's
+    // outputs as written at once and would reuse dead registers under data in flight)
+    if (load_next) {
+      xp[0] += RK;
+      xp[1] += RK;
     }
     __builtin_amdgcn_s_barrier();
     tslot += 4;
   }
 };
 
-template <bool RELU_IN>
+template <bool RELU_IN, bool HAS_RES>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * R_PIECE_BYTES];
   const int t = threadIdx.x;
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status
   st.tslot = 2;
 #ifdef RFD_GEMM_TRACE
   if (st.wave == 0 && st.lane == 0 && blockIdx.x < 512 && (blockIdx.x & 7) == 0)
-    st.trace = reinterpret_cast<unsigned long long *>(g.C) + (size_t)(blockIdx.x >> 3) * 128;
+    st.trace = reinterpret_cast<unsigned long long *>(g.C + (size_t)g.M * g.ldc) + (size_t)(blockIdx.x >> 3) * 128;
   GSTAMP(st, 0);
 #endif
   // prologue: x of pieces 0 and 1, W pieces 0..2
@@ -476,37 +484,59 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status
   wait_vm<0>();
 #ifdef RFD_GEMM_TRACE
   GSTAMP(st, 126 > st.tslot ? st.tslot : 125);
-  if (blockIdx.x < 512) return;
 #endif
 
-  // ---- epilogue: scale back, add bias / group bias / residual, ReLU; lane (n, half)
-  // holds channels 32 blk + 8 q + 4 half + (0..3) of its two rows: 16-byte accesses
+  // ---- epilogue.  Row-scattered 16-byte stores straight from the accumulator layout run
+  // at ~8 B/clk/CU (store-issue bound; measured 31k cycles for this tile).  Instead each
+  // wave transposes its 64 x 256 block through its own 32 KiB of the (now idle) ring, 128
+  // columns at a time, and writes 512 contiguous bytes per row: lane l of a row handles
+  // columns 4l..4l+3, so bias + group bias (never null here: the host passes a zero vector
+  // for an absent one) are loaded once per pass.  16-byte chunks are XOR-swizzled by the
+  // row (conflict-free on both sides, no padding).
+  __builtin_amdgcn_s_barrier();    // every wave's W transfers have landed: the ring is free
+  {
+    float *tr = reinterpret_cast<float *>(smem + st.wave * 32768);
+    const int l = st.lane & 31, rsel = st.lane >> 5;
+    // rows_per_group % 64 == 0 (checked by the host): one group per wave
+    const float *grow = g.gbias + (size_t)(m0 / g.rows_per_group) * g.N + n0 + 4 * l;
+    const float *brow = g.bias + n0 + 4 * l;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + 32 * i + n;
-    float *crow = g.C + (size_t)m * g.ldc + n0 + 4 * half;
-    const float *rrow = g.R ? g.R + (size_t)m * g.ldr + n0 + 4 * half : nullptr;
-    const float *grow = g.gbias ? g.gbias + (size_t)(m / g.rows_per_group) * g.N + n0 + 4 * half : nullptr;
-    const float *brow = g.bias ? g.bias + n0 + 4 * half : nullptr;
+    for (int p = 0; p < 2; ++p) {
+      const f32x4 cb = *reinterpret_cast<const f32x4 *>(brow + 128 * p) +
+                       *reinterpret_cast<const f32x4 *>(grow + 128 * p);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = 32 * b + 8 * q;
-        f32x4 v;
+        for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = st.acc[i][b][4 * q + e] * g.out_scale;
-        if (brow) v += *reinterpret_cast<const f32x4 *>(brow + c);
-        if (grow) v += *reinterpret_cast<const f32x4 *>(grow + c);
-        if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + c);
-        if (g.relu_out) {
+          for (int q = 0; q < 4; ++q) {
+            const int row = 32 * i + n, chunk = 8 * bb + 2 * q + half;
+            f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = st.acc[i][4 * p + bb][4 * q + e];
+            *reinterpret_cast<f32x4 *>(tr + row * 128 + ((chunk ^ (row & 31)) * 4)) = v;
+          }
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) {
+        const int row = 2 * j + rsel;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(tr + row * 128 + ((l ^ (row & 31)) * 4));
+        const size_t m = (size_t)(m0 + row);
+        f32x4 add = cb;
+        if (HAS_RES) add += *reinterpret_cast<const f32x4 *>(g.R + m * g.ldr + n0 + 128 * p + 4 * l);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = __builtin_fmaf(a[e], g.out_scale, add[e]);
+          if (g.relu_out) o[e] = o[e] > 0.f ? o[e] : 0.f;
         }
-        *reinterpret_cast<f32x4 *>(crow + c) = v;
+        *reinterpret_cast<f32x4 *>(g.C + m * g.ldc + n0 + 128 * p + 4 * l) = o;
       }
     }
   }
+#ifdef RFD_GEMM_TRACE
+  wait_vm<0>();
+  if (st.trace) st.trace[127] = __builtin_amdgcn_s_memtime();
+#endif
   (void)status;
 }
 
@@ -549,14 +579,22 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
   g.a_scale = ldexpf(1.f, sa); g.out_scale = ldexpf(1.f, -(sa + sw));
   const bool aligned = !(ldc & 3) && !(ldr & 3) && !((uintptr_t)C & 15) && !((uintptr_t)R & 15) &&
                        !((uintptr_t)bias & 15) && !((uintptr_t)gbias & 15);
-  if (M % RM == 0 && N % RN == 0 && K % 128 == 0 && aligned && getenv("RFD_GEMM_TILE_ONLY") == nullptr) {
+  if (M % RM == 0 && N % RN == 0 && N <= RFD_ZEROS_FLOATS && K % 128 == 0 && aligned &&
+      (!gbias || g.rows_per_group % 64 == 0) && getenv("RFD_GEMM_TILE_ONLY") == nullptr) {
     RfdWorkspace *ws;
     int rc = rfd_get_workspace(&ws);
     if (rc) return rc;
-    if (relu_in)
-      hipLaunchKernelGGL(gemm_rows_kernel<true>, dim3((M / RM) * (N / RN)), dim3(256), 0, (hipStream_t)stream, g, ws->status);
-    else
-      hipLaunchKernelGGL(gemm_rows_kernel<false>, dim3((M / RM) * (N / RN)), dim3(256), 0, (hipStream_t)stream, g, ws->status);
+    if (!g.bias) g.bias = ws->zeros;
+    if (!g.gbias) {
+      g.gbias = ws->zeros;
+      g.rows_per_group = M;      // every row reads group 0
+    }
+    const dim3 grid((M / RM) * (N / RN));
+    hipStream_t s = (hipStream_t)stream;
+    if (relu_in && R) hipLaunchKernelGGL((gemm_rows_kernel<true, true>), grid, dim3(256), 0, s, g, ws->status);
+    else if (relu_in) hipLaunchKernelGGL((gemm_rows_kernel<true, false>), grid, dim3(256), 0, s, g, ws->status);
+    else if (R) hipLaunchKernelGGL((gemm_rows_kernel<false, true>), grid, dim3(256), 0, s, g, ws->status);
+    else hipLaunchKernelGGL((gemm_rows_kernel<false, false>), grid, dim3(256), 0, s, g, ws->status);
   } else {
     hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, (hipStream_t)stream, g);
   }

@@ -135,8 +135,10 @@ __device__ __forceinline__ void epi_slice(int i, const f32x16 &x, const EpiTab &
   hiw[i] = __builtin_bit_cast(unsigned, h2);
   amax16 = pk_max_u16(amax16, hiw[i]);
   if (WITH_LO) {
-    // a - (float)hi with one rounding; fma(ext(f16), -1, f32) maps to v_fma_mix_f32
-    const float r0 = __builtin_fmaf((float)h2[0], -1.0f, a0), r1 = __builtin_fmaf((float)h2[1], -1.0f, a1);
+    // a - (float)hi (exact): one v_fma_mix_f32 per value, reading the f16 halves in place
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hiw[i]), "v"(a0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hiw[i]), "v"(a1));
     low[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
   } else {
     low[i] = 0u;
@@ -350,12 +352,11 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
             acc_next = mfma(cl, ahi[ks], acc_next);
           }
           if (ks < 8) epi_slice<X3>(ks, acc_cur, tb, hw, lw, amax16);  // VALU under the MFMAs
-          if (ks >= 8) {  // two LDS-DMA pieces per step in the steps without an epilogue slice
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-              const int j = 2 * (ks - 8) + jj, h = 2 * c + 3 + (j >> 3);
-              if (h < N_HALVES || has_next) dma_piece(packed, s_slots, h, j & 7, wave, lane);
-            }
+          {  // ONE LDS-DMA piece per step: four waves x 1 KiB per 96-cycle step keeps the
+             // address path at ~2/3 load (two per step in half of the steps saturated it and
+             // every transfer then cost its wave ~50 cycles of MFMA issue)
+            const int h = 2 * c + 3 + (ks >> 3);
+            if (h < N_HALVES || has_next) dma_piece(packed, s_slots, h, ks & 7, wave, lane);
           }
           // M r r v.. | M v.. | M v.. D : everything that is independent of the
           // accumulator chain goes into the 32-cycle gaps behind each MFMA
@@ -373,11 +374,10 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
           } else {
             if (X3) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
           }
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {

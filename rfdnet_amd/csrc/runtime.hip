@@ -29,6 +29,8 @@ int rfd_get_workspace(RfdWorkspace **out) {
                         sizeof(unsigned long long) * (size_t)FPS_RING * FPS_REGION_GRANULES));
     RFD_CHECK(hipMalloc((void **)&w->status, 64));
     RFD_CHECK(hipMemset(w->status, 0, 64));
+    RFD_CHECK(hipMalloc((void **)&w->zeros, sizeof(float) * RFD_ZEROS_FLOATS));
+    RFD_CHECK(hipMemset(w->zeros, 0, sizeof(float) * RFD_ZEROS_FLOATS));
     w->ring_pos.store(0);
     w->num_cu = 0;
     (void)hipDeviceGetAttribute(&w->num_cu, hipDeviceAttributeMultiprocessorCount, dev);

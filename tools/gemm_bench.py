@@ -2,6 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from rfdnet_amd import _lib
+if os.environ.get("RFD_LIB"): _lib.LIB_PATH = os.environ["RFD_LIB"]
 from rfdnet_amd import gemm
 
 torch.manual_seed(0)

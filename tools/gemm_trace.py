@@ -14,11 +14,12 @@ from rfdnet_amd import gemm
 torch.manual_seed(0)
 M, N, K = 262144, 1024, 512
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05
-out = torch.zeros(M, N, device="cuda")
+full = torch.zeros(M + 64, N, device="cuda")          # stamps land behind the M rows
+out = full[:M]
 for _ in range(2):
     gemm.linear(x, w, relu_in=True, out=out)
 torch.cuda.synchronize()
-raw = out.view(-1)[:64 * 256].cpu().numpy().view(np.uint64).reshape(64, 128)
+raw = full[M:].reshape(-1)[:64 * 256].cpu().numpy().view(np.uint64).reshape(64, 128)
 np.set_printoptions(linewidth=200)
 for wg in (0, 1, 5, 20, 40, 63):
     t = raw[wg].astype(np.int64)
@@ -29,3 +30,5 @@ for wg in (0, 1, 5, 20, 40, 63):
     print("  per step [s0 loop, wait8, s1 loop, barrier]:")
     print(d[:16])
     print("  mean", d.mean(0), "step total", d.sum(1).mean())
+    end_loop = t[2 + 4 * (K // 32)]
+    print("  whole WG", t[127] - t[0], " loop", end_loop - t[2], " epilogue", t[127] - end_loop)
