@@ -83,9 +83,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;        // wave position in the 2 x 2 grid
-  // n tiles fastest: the workgroups sharing an A tile run back to back (L2 reuse)
+  // the workgroups sharing an A tile (its n tiles) go to ONE XCD (own L2; workgroups are
+  // dealt round-robin to the 8 XCDs), at consecutive dispatch slots
   const int ntiles = g.N / BN;
-  const int ntile = blockIdx.x % ntiles, mtile = blockIdx.x / ntiles;
+  int ntile, mtile;
+  if ((g.M / BM) % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    ntile = j % ntiles;
+    mtile = (j / ntiles) * 8 + xcd;
+  } else {
+    ntile = blockIdx.x % ntiles;
+    mtile = blockIdx.x / ntiles;
+  }
   const int m0 = mtile * BM, n0 = ntile * BN;
   const int kiters = g.K / BK;
 
@@ -431,7 +440,21 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status
   st.a_scale = g.a_scale;
   const int half = st.lane >> 5, n = st.lane & 31;
   const int ntiles = g.N / RN;
-  const int ntile = blockIdx.x % ntiles, mtile = blockIdx.x / ntiles;   // n tiles of one row tile back to back
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the n tiles of
+  // one row tile go to ONE XCD, at consecutive dispatch slots, so the 256 x K activation
+  // tile is fetched from HBM once instead of once per n tile.
+  int ntile, mtile;
+  {
+    const int mtiles = g.M / RM;
+    if (mtiles % 8 == 0) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      ntile = j % ntiles;
+      mtile = (j / ntiles) * 8 + xcd;
+    } else {
+      ntile = blockIdx.x % ntiles;
+      mtile = blockIdx.x / ntiles;
+    }
+  }
   const int m0 = mtile * RM + st.wave * 64, n0 = ntile * RN;
   const int np = g.K / RK;
   st.wp = reinterpret_cast<const char *>(g.Wp) + ((size_t)g.N * g.K * 2 + (size_t)ntile * np * (R_PIECE_BYTES / 2)) * 2;
