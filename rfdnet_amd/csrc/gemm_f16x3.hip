@@ -214,15 +214,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
 //
 // The 128 x 128 kernel above re-reads 32 KiB of operands per 3 MFLOP issued and
 // both operands pass through LDS; at the encoder's shapes it is bound by the
-// L2 -> CU traffic, not by the matrix pipe.  Here a workgroup owns a 256 x 256
-// output tile and each WAVE 64 rows x 256 columns = 2 x 8 accumulator blocks (256
-// accumulator registers per lane):
+// L2 -> CU traffic, not by the matrix pipe.  Here a workgroup (8 waves) owns a 256 x 256
+// output tile and each WAVE 32 rows x 256 columns = 8 accumulator blocks:
 //   * activations never touch LDS: lane (n, h) loads 16 consecutive k of ITS rows
 //     (one contiguous 64-byte chunk per row and 32-wide k piece), rectifies / scales /
 //     splits them in registers and uses them directly as B fragments -- the k order
 //     inside a piece is whatever that makes it (the packed W uses the same order);
 //   * W streams through a 4-slot LDS ring of 32-KiB pieces (LDS-DMA, three pieces
-//     ahead), one fragment pair feeding 6 MFMAs (two row groups).
+//     ahead);
+//   * the epilogue transposes each wave's block through the idle ring so that every row
+//     is written in 512-byte runs (row-scattered 16-byte stores ran at ~8 B/clk/CU).
 // Per 32-wide k piece a CU moves 64 KiB (32 KiB x fp32, 32 KiB W) for 12.6 MFLOP issued.
 constexpr int RM = 256, RN = 256, RK = 32;
 constexpr int R_PIECE_BYTES = 32 * 1024;
@@ -250,199 +251,27 @@ __global__ void gemm_pack_rows_kernel(int N, int K, int sw, const float *__restr
   packed[e] = split == 0 ? hi : lo;
 }
 
-#ifdef RFD_GEMM_TRACE
-// debug build only (tools/gemm_trace.py): wave 0 / lane 0 of some workgroups write
-// s_memtime stamps BEHIND the M rows of C (the tool allocates the extra rows)
-#define GSTAMP(st_, slot)                                                           \
-  do {                                                                               \
-    if ((st_).trace && (slot) < 126) (st_).trace[(slot)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define GSTAMP(st_, slot) do { } while (0)
-#endif
-
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool RELU_IN>
-struct RowsState {
-  f32x16 acc[2][8];
-  f32x4 xr[2][2][4];        // [piece & 1][row group][16 consecutive k of this lane]
-  half8 bh[2], bl[2];       // B fragments of the current k-step, per row group
-  unsigned nh[2][4], nl[2][4];
-  const float *xp[2];       // this lane's two rows, at the NEXT piece to load
-  const char *wp;           // packed W of this n tile (wave-uniform)
-  unsigned char *ring;
-  float a_scale;
-  int wave, lane;
-  unsigned lane16;
-  unsigned long long *trace;
-  int tslot;
-
-  // 16 bytes of row group g's next piece (q = 0..3).  Opaque to the compiler (its own wait
-  // insertion would drain vmcnt and the LDS-DMA pipeline with it); the explicit waits in
-  // step() cover these loads.
-  template <int Q>
-  __device__ __forceinline__ void load_x1(int slot, int g) {
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(xr[slot][g][Q]) : "v"(xp[g]), "n"(16 * Q) : "memory");
-  }
-  __device__ __forceinline__ void load_x_pair(int slot, int i) {   // loads 2i, 2i+1 of the 8
-    switch (i) {
-      case 0: load_x1<0>(slot, 0); load_x1<1>(slot, 0); break;
-      case 1: load_x1<2>(slot, 0); load_x1<3>(slot, 0); break;
-      case 2: load_x1<0>(slot, 1); load_x1<1>(slot, 1); break;
-      default: load_x1<2>(slot, 1); load_x1<3>(slot, 1); break;
-    }
-  }
-  __device__ __forceinline__ void load_x(int slot) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) load_x_pair(slot, i);
-  }
-  // One 1-KiB transfer of the piece at byte offset `poff` of this n tile's stream.  The
-  // instruction's immediate offset moves the global AND the LDS address, so a step needs
-  // two address pairs (jj < 4, jj >= 4) instead of eight.
-  template <int JJ>
-  __device__ __forceinline__ void dma1(unsigned poff, int slot) {
-    const char *src = wp + poff + (wave * 8 + JJ) * 1024;
-    __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane16),
-                                     (lds_void *)(ring + slot * R_PIECE_BYTES + (wave * 8 + JJ) * 1024), 16,
-                                     0, 0);
-  }
-  // jj is a constant after unrolling: the switch folds to the one instruction
-  __device__ __forceinline__ void dma_jj(unsigned poff, int slot, int jj) {
-    switch (jj) {
-      case 0: dma1<0>(poff, slot); break;
-      case 1: dma1<1>(poff, slot); break;
-      case 2: dma1<2>(poff, slot); break;
-      case 3: dma1<3>(poff, slot); break;
-      case 4: dma1<4>(poff, slot); break;
-      case 5: dma1<5>(poff, slot); break;
-      case 6: dma1<6>(poff, slot); break;
-      default: dma1<7>(poff, slot); break;
-    }
-  }
-  // two of the 8 inputs of (slot, k-step s, row group g) -> word i of the next B pair
-  __device__ __forceinline__ void conv_slice(int slot, int s, int g, int i) {
-    const f32x4 v = xr[slot][g][2 * s + (i >> 1)];
-    float a0 = v[2 * (i & 1)] * a_scale, a1 = v[2 * (i & 1) + 1] * a_scale;
-    if (RELU_IN) {
-      a0 = a0 > 0.f ? a0 : 0.f;
-      a1 = a1 > 0.f ? a1 : 0.f;
-    }
-    const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(a0, a1));
-    const float r0 = a0 - (float)h2[0], r1 = a1 - (float)h2[1];
-    nh[g][i] = __builtin_bit_cast(unsigned, h2);
-    nl[g][i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-  }
-  __device__ __forceinline__ void conv_finish() {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      bh[g] = __builtin_bit_cast(half8, u32x4{nh[g][0], nh[g][1], nh[g][2], nh[g][3]});
-      bl[g] = __builtin_bit_cast(half8, u32x4{nl[g][0], nl[g][1], nl[g][2], nl[g][3]});
-    }
-  }
-
-  // one 32-wide k piece P (ring slot P & 3, x slot P & 1); `dpiece` = piece whose W is
-  // fetched now; x of piece P+2 is fetched half-way (load_next: that piece exists)
-  template <int PS>
-  __device__ __forceinline__ void step(unsigned dpiece, bool load_next) {
-    constexpr int XS = PS & 1;
-    GSTAMP(*this, tslot);
-    const half8 *w = reinterpret_cast<const half8 *>(ring + PS * R_PIECE_BYTES) + lane;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      // two column blocks x two row groups = FOUR independent accumulators in rotation
-      // (a dependent MFMA issued with only one other MFMA in between still waits for its
-      // producer); the next pair's fragments are read in the shadow
-      half8 c[2][2], nx[2][2];
-#pragma unroll
-      for (int o = 0; o < 2; ++o) {
-        c[o][0] = w[(s * 16 + 2 * o) * 64];
-        c[o][1] = w[(s * 16 + 2 * o + 1) * 64];
-      }
-      const half8 h0 = bh[0], l0 = bl[0], h1 = bh[1], l1 = bl[1];
-#pragma unroll
-      for (int bp = 0; bp < 4; ++bp) {
-        if (bp < 3) {
-#pragma unroll
-          for (int o = 0; o < 2; ++o) {
-            nx[o][0] = w[(s * 16 + 4 * bp + 4 + 2 * o) * 64];
-            nx[o][1] = w[(s * 16 + 4 * bp + 5 + 2 * o) * 64];
-          }
-        }
-        const int b0 = 2 * bp, b1 = 2 * bp + 1;
-        acc[0][b0] = mfma(c[0][0], h0, acc[0][b0]);
-        acc[1][b0] = mfma(c[0][0], h1, acc[1][b0]);
-        acc[0][b1] = mfma(c[1][0], h0, acc[0][b1]);
-        acc[1][b1] = mfma(c[1][0], h1, acc[1][b1]);
-        acc[0][b0] = mfma(c[0][0], l0, acc[0][b0]);
-        acc[1][b0] = mfma(c[0][0], l1, acc[1][b0]);
-        acc[0][b1] = mfma(c[1][0], l0, acc[0][b1]);
-        acc[1][b1] = mfma(c[1][0], l1, acc[1][b1]);
-        acc[0][b0] = mfma(c[0][1], h0, acc[0][b0]);
-        acc[1][b0] = mfma(c[0][1], h1, acc[1][b0]);
-        acc[0][b1] = mfma(c[1][1], h0, acc[0][b1]);
-        acc[1][b1] = mfma(c[1][1], h1, acc[1][b1]);
-        // the next k-step's B pairs: k-step 1 of this piece, or k-step 0 of the next
-        conv_slice(s == 0 ? XS : (XS ^ 1), s ^ 1, bp >> 1, 2 * (bp & 1));
-        conv_slice(s == 0 ? XS : (XS ^ 1), s ^ 1, bp >> 1, 2 * (bp & 1) + 1);
-        // x of piece P+2, two 16-byte loads per block pair of k-step 1 (this piece's x
-        // slot is dead after k-step 0), ahead of this iteration's W transfer
-        if (s == 1 && load_next) load_x_pair(XS, bp);
-        dma_jj(dpiece, (PS + 3) & 3, 4 * s + bp);
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (q == 6) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (bp < 3) {
-#pragma unroll
-          for (int o = 0; o < 2; ++o) {
-            c[o][0] = nx[o][0];
-            c[o][1] = nx[o][1];
-          }
-        }
-      }
-      conv_finish();
-      GSTAMP(*this, tslot + 1 + 2 * s);
-      if (s == 0) {
-        // everything but the last five W transfers has landed: the x of piece P+1
-        // (its last load went out before the last transfer of the previous step)
-        wait_vm<5>();
-        GSTAMP(*this, tslot + 2);
-      }
-    }
-    // (never issue a load whose result is not consumed: the compiler treats the asm's
-    // outputs as written at once and would reuse dead registers under data in flight)
-    if (load_next) {
-      xp[0] += RK;
-      xp[1] += RK;
-    }
-    __builtin_amdgcn_s_barrier();
-    tslot += 4;
-  }
-};
-
+// 8 waves per workgroup: a wave owns 32 rows x 256 columns (8 accumulator blocks, <= 256
+// registers), so TWO waves share each SIMD: while one is stuck issuing a vector-memory
+// instruction, parked at a wait or in its epilogue, the other keeps the matrix pipe busy
+// (vs 4 waves x 64 rows: +3 % on the loop-bound shapes, +23 % with a residual to read).
+// The x loads are opaque asm (the compiler's own wait insertion would drain vmcnt and the
+// LDS-DMA pipeline with it) and are only issued when their result is consumed: the
+// compiler treats an asm's outputs as written at once and would otherwise reuse dead
+// registers under data still in flight.
 template <bool RELU_IN, bool HAS_RES>
-__global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status) {
+__global__ __launch_bounds__(512) void gemm_rows8_kernel(Args g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * R_PIECE_BYTES];
-  const int t = threadIdx.x;
-  RowsState<RELU_IN> st;
-  st.lane = t & 63;
-  st.wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  st.lane16 = (unsigned)st.lane * 16u;
-  st.ring = smem;
-  st.a_scale = g.a_scale;
-  const int half = st.lane >> 5, n = st.lane & 31;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int half = lane >> 5, n = lane & 31;
   const int ntiles = g.N / RN;
-  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the n tiles of
-  // one row tile go to ONE XCD, at consecutive dispatch slots, so the 256 x K activation
-  // tile is fetched from HBM once instead of once per n tile.
   int ntile, mtile;
   {
     const int mtiles = g.M / RM;
@@ -455,72 +284,130 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status
       mtile = blockIdx.x / ntiles;
     }
   }
-  const int m0 = mtile * RM + st.wave * 64, n0 = ntile * RN;
+  const int m0 = mtile * RM + wave * 32, n0 = ntile * RN;
   const int np = g.K / RK;
-  st.wp = reinterpret_cast<const char *>(g.Wp) + ((size_t)g.N * g.K * 2 + (size_t)ntile * np * (R_PIECE_BYTES / 2)) * 2;
-  st.xp[0] = g.A + (size_t)(m0 + n) * g.lda + 16 * half;
-  st.xp[1] = g.A + (size_t)(m0 + 32 + n) * g.lda + 16 * half;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) st.acc[i][b] = f32x16{0.f};
+  const char *wp = reinterpret_cast<const char *>(g.Wp) +
+                   ((size_t)g.N * g.K * 2 + (size_t)ntile * np * (R_PIECE_BYTES / 2)) * 2;
+  const float *xp = g.A + (size_t)(m0 + n) * g.lda + 16 * half;
 
-  st.trace = nullptr;
-  st.tslot = 2;
-#ifdef RFD_GEMM_TRACE
-  if (st.wave == 0 && st.lane == 0 && blockIdx.x < 512 && (blockIdx.x & 7) == 0)
-    st.trace = reinterpret_cast<unsigned long long *>(g.C + (size_t)g.M * g.ldc) + (size_t)(blockIdx.x >> 3) * 128;
-  GSTAMP(st, 0);
-#endif
-  // prologue: x of pieces 0 and 1, W pieces 0..2
-  st.load_x(0);
-  st.xp[0] += RK;
-  st.xp[1] += RK;
-  st.load_x(1);
-  st.xp[0] += RK;
-  st.xp[1] += RK;
+  f32x16 acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = f32x16{0.f};
+  f32x4 xr[2][4];
+  half8 bh, bl;
+  unsigned nh[4], nl[4];
+
+  auto load_x2 = [&](int slot, int i) {   // loads 2i, 2i+1 of the 4 of a piece
+    if (i == 0)
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                   : "=&v"(xr[slot][0]), "=&v"(xr[slot][1]) : "v"(xp) : "memory");
+    else
+      asm volatile("global_load_dwordx4 %0, %2, off offset:32\n\tglobal_load_dwordx4 %1, %2, off offset:48"
+                   : "=&v"(xr[slot][2]), "=&v"(xr[slot][3]) : "v"(xp) : "memory");
+  };
+  auto dma = [&](unsigned poff, int slot, int jj) {
+    const char *src = wp + poff + (wave * 4 + jj) * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane16),
+                                     (lds_void *)(smem + slot * R_PIECE_BYTES + (wave * 4 + jj) * 1024), 16, 0, 0);
+  };
+  auto conv_slice = [&](int slot, int s, int i) {
+    const f32x4 v = xr[slot][2 * s + (i >> 1)];
+    float a0 = v[2 * (i & 1)] * g.a_scale, a1 = v[2 * (i & 1) + 1] * g.a_scale;
+    if (RELU_IN) {
+      a0 = a0 > 0.f ? a0 : 0.f;
+      a1 = a1 > 0.f ? a1 : 0.f;
+    }
+    const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+    const float r0 = a0 - (float)h2[0], r1 = a1 - (float)h2[1];
+    nh[i] = __builtin_bit_cast(unsigned, h2);
+    nl[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+  };
+  auto conv_finish = [&]() {
+    bh = __builtin_bit_cast(half8, u32x4{nh[0], nh[1], nh[2], nh[3]});
+    bl = __builtin_bit_cast(half8, u32x4{nl[0], nl[1], nl[2], nl[3]});
+  };
+
+  load_x2(0, 0);
+  load_x2(0, 1);
+  xp += RK;
+  load_x2(1, 0);
+  load_x2(1, 1);
+  xp += RK;
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) st.dma_jj(p * R_PIECE_BYTES, p, jj);
+    for (int jj = 0; jj < 4; ++jj) dma(p * R_PIECE_BYTES, p, jj);
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) st.conv_slice(0, 0, i >> 2, i & 3);
-  st.conv_finish();
-  GSTAMP(st, 1);
+  for (int i = 0; i < 4; ++i) conv_slice(0, 0, i);
+  conv_finish();
 
-  // x of piece p+2 is fetched in step p (if it exists);
-  // W of piece p+3 likewise (wraps to an already consumed piece at the end)
   const unsigned wbytes = (unsigned)np * R_PIECE_BYTES;
-  unsigned doff = 3 * R_PIECE_BYTES;          // np >= 4
+  unsigned doff = 3 * R_PIECE_BYTES;
   for (int p4 = 0; p4 < np; p4 += 4) {
-    st.template step<0>(doff, p4 + 2 < np);
-    doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
-    st.template step<1>(doff, p4 + 3 < np);
-    doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
-    st.template step<2>(doff, p4 + 4 < np);
-    doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
-    st.template step<3>(doff, p4 + 5 < np);
-    doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int xs = ps & 1;
+      const bool load_next = p4 + ps + 2 < np;
+      const half8 *w = reinterpret_cast<const half8 *>(smem + ps * R_PIECE_BYTES) + lane;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        half8 c[2][2], nx[2][2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          c[o][0] = w[(s * 16 + 2 * o) * 64];
+          c[o][1] = w[(s * 16 + 2 * o + 1) * 64];
+        }
+        const half8 h0 = bh, l0 = bl;
+#pragma unroll
+        for (int bp = 0; bp < 4; ++bp) {
+          if (bp < 3) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+              nx[o][0] = w[(s * 16 + 4 * bp + 4 + 2 * o) * 64];
+              nx[o][1] = w[(s * 16 + 4 * bp + 5 + 2 * o) * 64];
+            }
+          }
+          const int b0 = 2 * bp, b1 = 2 * bp + 1;
+          acc[b0] = mfma(c[0][0], h0, acc[b0]);
+          acc[b1] = mfma(c[1][0], h0, acc[b1]);
+          acc[b0] = mfma(c[0][0], l0, acc[b0]);
+          acc[b1] = mfma(c[1][0], l0, acc[b1]);
+          acc[b0] = mfma(c[0][1], h0, acc[b0]);
+          acc[b1] = mfma(c[1][1], h0, acc[b1]);
+          conv_slice(s == 0 ? xs : (xs ^ 1), s ^ 1, bp);
+          if (s == 1 && load_next && bp < 2) load_x2(xs, bp);
+          if (!(bp & 1)) dma(doff, (ps + 3) & 3, 2 * s + (bp >> 1));
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (q == 3 && !(bp & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (bp < 3) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+              c[o][0] = nx[o][0];
+              c[o][1] = nx[o][1];
+            }
+          }
+        }
+        conv_finish();
+        if (s == 0) wait_vm<3>();
+      }
+      if (load_next) xp += RK;
+      doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
+      __builtin_amdgcn_s_barrier();
+    }
   }
   wait_vm<0>();
-#ifdef RFD_GEMM_TRACE
-  GSTAMP(st, 126 > st.tslot ? st.tslot : 125);
-#endif
-
-  // ---- epilogue.  Row-scattered 16-byte stores straight from the accumulator layout run
-  // at ~8 B/clk/CU (store-issue bound; measured 31k cycles for this tile).  Instead each
-  // wave transposes its 64 x 256 block through its own 32 KiB of the (now idle) ring, 128
-  // columns at a time, and writes 512 contiguous bytes per row: lane l of a row handles
-  // columns 4l..4l+3, so bias + group bias (never null here: the host passes a zero vector
-  // for an absent one) are loaded once per pass.  16-byte chunks are XOR-swizzled by the
-  // row (conflict-free on both sides, no padding).
-  __builtin_amdgcn_s_barrier();    // every wave's W transfers have landed: the ring is free
+  __builtin_amdgcn_s_barrier();
   {
-    float *tr = reinterpret_cast<float *>(smem + st.wave * 32768);
-    const int l = st.lane & 31, rsel = st.lane >> 5;
-    // rows_per_group % 64 == 0 (checked by the host): one group per wave
+    float *tr = reinterpret_cast<float *>(smem + wave * 16384);
+    const int l = lane & 31, rsel = lane >> 5;
     const float *grow = g.gbias + (size_t)(m0 / g.rows_per_group) * g.N + n0 + 4 * l;
     const float *brow = g.bias + n0 + 4 * l;
 #pragma unroll
@@ -528,21 +415,19 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status
       const f32x4 cb = *reinterpret_cast<const f32x4 *>(brow + 128 * p) +
                        *reinterpret_cast<const f32x4 *>(grow + 128 * p);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
+        for (int q = 0; q < 4; ++q) {
+          const int chunk = 8 * bb + 2 * q + half;
+          f32x4 v;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 32 * i + n, chunk = 8 * bb + 2 * q + half;
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = st.acc[i][4 * p + bb][4 * q + e];
-            *reinterpret_cast<f32x4 *>(tr + row * 128 + ((chunk ^ (row & 31)) * 4)) = v;
-          }
+          for (int e = 0; e < 4; ++e) v[e] = acc[4 * p + bb][4 * q + e];
+          *reinterpret_cast<f32x4 *>(tr + n * 128 + ((chunk ^ n) * 4)) = v;
+        }
 #pragma unroll 8
-      for (int j = 0; j < 32; ++j) {
+      for (int j = 0; j < 16; ++j) {
         const int row = 2 * j + rsel;
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(tr + row * 128 + ((l ^ (row & 31)) * 4));
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(tr + row * 128 + ((l ^ row) * 4));
         const size_t m = (size_t)(m0 + row);
         f32x4 add = cb;
         if (HAS_RES) add += *reinterpret_cast<const f32x4 *>(g.R + m * g.ldr + n0 + 128 * p + 4 * l);
@@ -556,11 +441,6 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(Args g, unsigned *status
       }
     }
   }
-#ifdef RFD_GEMM_TRACE
-  wait_vm<0>();
-  if (st.trace) st.trace[127] = __builtin_amdgcn_s_memtime();
-#endif
-  (void)status;
 }
 
 }  // namespace
@@ -614,10 +494,10 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
     }
     const dim3 grid((M / RM) * (N / RN));
     hipStream_t s = (hipStream_t)stream;
-    if (relu_in && R) hipLaunchKernelGGL((gemm_rows_kernel<true, true>), grid, dim3(256), 0, s, g, ws->status);
-    else if (relu_in) hipLaunchKernelGGL((gemm_rows_kernel<true, false>), grid, dim3(256), 0, s, g, ws->status);
-    else if (R) hipLaunchKernelGGL((gemm_rows_kernel<false, true>), grid, dim3(256), 0, s, g, ws->status);
-    else hipLaunchKernelGGL((gemm_rows_kernel<false, false>), grid, dim3(256), 0, s, g, ws->status);
+    if (relu_in && R) hipLaunchKernelGGL((gemm_rows8_kernel<true, true>), grid, dim3(512), 0, s, g);
+    else if (relu_in) hipLaunchKernelGGL((gemm_rows8_kernel<true, false>), grid, dim3(512), 0, s, g);
+    else if (R) hipLaunchKernelGGL((gemm_rows8_kernel<false, true>), grid, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm_rows8_kernel<false, false>), grid, dim3(512), 0, s, g);
   } else {
     hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, (hipStream_t)stream, g);
   }

@@ -32,7 +32,7 @@ def _packed(weight):
         with torch.cuda.device(w.device):
             rc = _lib.lib().rfd_gemm_pack_w(N, K, sw, w.data_ptr(), buf.data_ptr(), _lib.current_stream())
         _lib.check(rc, "rfd_gemm_pack_w")
-        hit = (buf, sw, w)            # keep w alive: the key is its data_ptr
+        hit = (buf, sw, weight)       # keep the keyed tensor alive: its address must not be reused
         if len(_cache) > 256:
             _cache.clear()
         _cache[key] = hit

@@ -15,7 +15,6 @@ from . import _lib, occ_fold
 
 HIDDEN = 256
 TILE = 128
-_cache = {}
 
 
 def usable(x, rows_per_group):
@@ -25,9 +24,11 @@ def usable(x, rows_per_group):
 
 
 def _packed(block, k_in):
+    """Packed weight stream of `block`, cached ON the block (a cache keyed by id() or
+    data_ptr() alone would alias a later module that reuses the address)."""
     ps = (block.fc_0.weight, block.shortcut.weight, block.fc_1.weight)
-    key = (id(block), k_in) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
-    hit = _cache.get(id(block))
+    key = (k_in,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+    hit = block.__dict__.get('_rfd_resblock')
     if hit is None or hit[0] != key:
         w0, ws, w1 = (p.detach() for p in ps)
         assert w0.shape[0] == HIDDEN and ws.shape[0] == HIDDEN and tuple(w1.shape) == (HIDDEN, HIDDEN)
@@ -41,7 +42,7 @@ def _packed(block, k_in):
                                               _lib.current_stream())
         _lib.check(rc, "rfd_resblock_pack")
         hit = (key, buf, kw0, kw1)
-        _cache[id(block)] = hit
+        block.__dict__['_rfd_resblock'] = hit
     return hit[1:]
 
 
