@@ -74,6 +74,20 @@ def main():
             res["decode_%s_TFLOPs" % name] = K * T * 1312768 / t / 1e9
             res["decode_%s_Mpts_s" % name] = K * T / t / 1e3
         res["fold_ms"] = timeit(lambda: dec.fold(z, c))
+        # SURVEY config 3: decoder stress, 256 x 262 144 uniform points (88.1 TFLOP algorithmic)
+        T3 = 262144
+        p3 = (torch.rand(K * T3, 3, device="cuda") - 0.5) * 1.1
+        tp3 = torch.arange(K, dtype=torch.int32, device="cuda").repeat_interleave(T3 // 128)
+        for mode, name in ((MODE_F16X3, "f16x3"), (MODE_F16X1, "f16x1")):
+            t = timeit(lambda: dec.decode_tiles(p3, tp3, table, fcp, mode=mode), warm=1, it=2)
+            res["config3_decode_%s_256x262144_ms" % name] = t
+            res["config3_decode_%s_TFLOPs" % name] = K * T3 * 1312768 / t / 1e9
+            res["config3_decode_%s_frac_of_2500" % name] = K * T3 * 1312768 / t / 1e9 / 2500.0
+        del p3, tp3
+    res["fps_sa1_Mupdates_per_s"] = 80000 * 2047 / res["fps_80000_2048_ms"] / 1e3
+    res["fps_sa1_onchip_GBps"] = 16.0 * 80000 * 2047 / res["fps_80000_2048_ms"] / 1e6
+    res["ballq_sa1_Gtests_per_s_upper"] = 2048 * 80000 / res["ballq_sa1_ms"] / 1e6
+    res["group_sa2_B32_frac_of_8TBps"] = res["group_sa2_B32_GBps"] / 8000.0
     from rfdnet_amd import gemm
     for (M, N, K) in ((262144, 1024, 1024), (262144, 1024, 512), (262144, 512, 512)):
         xa = torch.randn(M, K, device="cuda")
