@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_QUERY = 2 * 3 * 256 + 10 * 2 * 256 * 256 + 2 * 256        # 1 312 768
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, MI355X_MICROARCH.md
+TRAFFIC_BYTES_PER_QUERY = 20.9  # measured (PMC), see roofline.traffic_source
 
 
 def parse():
@@ -361,7 +362,13 @@ def main():
                        "parallelism": "scenes sharded across GPUs, dp%d; %d scenes in flight per GPU" % (world, S)},
             "roofline": {"bound": "mfma", "kernel": "occ_decode_kernel<%d>" % (3 if args.mode == "f16x3" else 1),
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / MFMA_PEAK_TFLOPS,
+                         # HBM bytes per launch: the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
+                         # rocprofv3 --pmc runs, profiles/r01_j_decoder_pmc.txt) give 20.9 B per query
+                         # point (16 B algorithmic); scaled to this run's average launch
+                         "traffic": TRAFFIC_BYTES_PER_QUERY * dec_pts / dec_launches if dec_launches else None,
+                         "traffic_source": "20.9 B/query from rocprofv3 PMC passes on the same kernel "
+                                           "(profiles/r01_j_decoder_pmc.txt) x queries per launch",
                          "launches": int(dec_launches),
                          "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
                          "algorithmic_flop_per_launch": dec_pts * FLOP_PER_QUERY / dec_launches if dec_launches else None,
