@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librfd_hip.so")
+# RFD_HIP_LIB: load another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("RFD_HIP_LIB") or os.path.join(_HERE, "lib", "librfd_hip.so")
 
 _f = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 _i = C.c_int
