@@ -131,6 +131,20 @@ int rfd_device_status(void);
 /* "gfx950" etc. of the code object actually loaded. */
 const char *rfd_build_arch(void);
 
+/* One set-abstraction layer after the ball query, fused: group -> centre-subtract
+ * [* (1.0f / radius)] -> concat(xyz first) -> 3 x [1x1 conv + BN(eval) + ReLU] -> max over
+ * the nsample neighbours, without materialising the (3+c, m, nsample) tensor.  Replaces
+ * PointnetSAModuleVotes.forward after the grouper's ball query (pointnet2_modules.py:219-255,
+ * pointnet2_utils.py:333-344, build_shared_mlp :9-19) at inference; exact-fp32 MFMA.
+ * w1..w3: BN-folded weights re-laid by the host (rfdnet_amd/sa_fused.py documents the layout),
+ * b1..b3 folded biases; out (b, c3, m).  nsample in {16, 32, 64}; instantiated widths:
+ * (3+c_feat -> c1, c2, c3) = (4 -> 64,64,128), (131 -> 128,128,256), (259 -> 128,128,256),
+ * (259 -> 128,128,128). */
+int rfd_sa_fused(int b, int n, int m, int nsample, int c_feat, float radius, int normalize_xyz,
+                 const float *xyz, const float *new_xyz, const float *features, const int *idx,
+                 int c1, int c2, int c3, const float *w1, const float *b1, const float *w2,
+                 const float *b2, const float *w3, const float *b3, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

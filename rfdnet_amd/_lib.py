@@ -28,6 +28,7 @@ SIGNATURES = {
     "three_interpolate_grad_kernel_wrapper": [_i, _i, _i, _i, _f, _f, _f, _f, _f],
     "rfd_group_concat": [_i, _i, _i, _i, _i, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f],
     "rfd_furthest_point_sampling_gather": [_i, _i, _i, _f, _f, _f, _f, _f],
+    "rfd_sa_fused": [_i, _i, _i, _i, _i, _fl, _i, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f],
     "rfd_occ_pack_weights": [_f, _f, C.POINTER(C.c_int), _i, _f, _f],
     "rfd_occ_decode": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],
     "rfd_make_grid_points": [_i, _fl, _fl, _fl, _f, _i, _f],

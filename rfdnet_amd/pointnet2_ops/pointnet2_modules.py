@@ -70,6 +70,14 @@ class PointnetSAModuleVotes(nn.Module):
             else:
                 assert inds.shape[1] == self.npoint
                 new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        from .. import sa_fused
+        if (self.npoint is not None and sa_fused.usable(self.mlp_module, features, self.nsample, self.pooling,
+                                                        self.use_xyz)):
+            # inference: grouping + shared MLP + max pool in ONE kernel (csrc/sa_fused.hip);
+            # the (3+C, npoint, nsample) tensor is never materialised
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+            return new_xyz, sa_fused.forward(self.mlp_module, xyz, new_xyz, features, idx, self.radius,
+                                             self.normalize_xyz), inds
         grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
         new_features = self.mlp_module(grouped_features)          # (B, C', npoint, nsample)
         if self.pooling == 'max':
