@@ -155,6 +155,39 @@ def three_nn(unknown, known):
     return d2, idx
 
 
+def chamfer_forward(xyz1, xyz2):
+    """xyz1 (B,n,3), xyz2 (B,m,3) -> dist1 (B,n) f32, idx1 (B,n) i32, dist2 (B,m), idx2 (B,m)
+    (chamfer_distance.cpp:60-115)."""
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.zeros((b, n), dtype=np.float32)
+    i1 = np.zeros((b, n), dtype=np.int32)
+    d2 = np.zeros((b, m), dtype=np.float32)
+    i2 = np.zeros((b, m), dtype=np.int32)
+    lib().oracle_chamfer_forward(b, n, m, p1, p2, d1.ctypes.data_as(_f32p), i1.ctypes.data_as(_i32p),
+                                 d2.ctypes.data_as(_f32p), i2.ctypes.data_as(_i32p))
+    return d1, i1, d2, i2
+
+
+def chamfer_backward(xyz1, xyz2, gd1, idx1, gd2, idx2):
+    """-> grad_xyz1 (B,n,3), grad_xyz2 (B,m,3) (chamfer_distance.cpp:118-180)."""
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    gd1, q1 = _f(gd1)
+    gd2, q2 = _f(gd2)
+    idx1, j1 = _i(idx1)
+    idx2, j2 = _i(idx2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = np.zeros((b, n, 3), dtype=np.float32)
+    g2 = np.zeros((b, m, 3), dtype=np.float32)
+    lib().oracle_chamfer_backward(b, n, m, p1, p2, q1, j1, q2, j2, g1.ctypes.data_as(_f32p),
+                                  g2.ctypes.data_as(_f32p))
+    return g1, g2
+
+
 def three_interpolate(points, idx, weight):
     """points (B,C,m), idx/weight (B,n,3) -> (B,C,n)."""
     points, pp = _f(points)

@@ -680,3 +680,69 @@ ORACLE_API void oracle_mise_to_dense(void *h, double *out) {
         if (isnan(AT(i, j, k))) AT(i, j, k) = AT(i, j, k - 1);
 #undef AT
 }
+
+/* ---- Chamfer distance (external/pyTorchChamferDistance/chamfer_distance/chamfer_distance.cpp) ----
+ * Restates the reference's OWN CPU implementation: nnsearch (:60-87: float products summed left
+ * to right, compared as double, `k == 0 || d < best` => lowest index wins ties) and the backward
+ * loops (:118-180: g = 2 grad; += on the point, -= on its nearest neighbour, first the xyz1 pass
+ * then the xyz2 pass, sequential order).  Pinned bit-exactly against that implementation built
+ * from the reference source (oracle/build_ref_chamfer.py) and by tests/golden/F_CD.npz. */
+static void oracle_nnsearch(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
+                            int *idx) {
+  for (int i = 0; i < b; ++i) {
+#pragma omp parallel for
+    for (int j = 0; j < n; ++j) {
+      const float x1 = xyz1[((size_t)i * n + j) * 3 + 0];
+      const float y1 = xyz1[((size_t)i * n + j) * 3 + 1];
+      const float z1 = xyz1[((size_t)i * n + j) * 3 + 2];
+      double best = 0;
+      int besti = 0;
+      for (int k = 0; k < m; ++k) {
+        const float x2 = xyz2[((size_t)i * m + k) * 3 + 0] - x1;
+        const float y2 = xyz2[((size_t)i * m + k) * 3 + 1] - y1;
+        const float z2 = xyz2[((size_t)i * m + k) * 3 + 2] - z1;
+        const float df = x2 * x2 + y2 * y2 + z2 * z2;
+        const double d = df;
+        if (k == 0 || d < best) {
+          best = d;
+          besti = k;
+        }
+      }
+      dist[(size_t)i * n + j] = (float)best;
+      idx[(size_t)i * n + j] = besti;
+    }
+  }
+}
+
+ORACLE_API void oracle_chamfer_forward(int b, int n, int m, const float *xyz1, const float *xyz2,
+                                       float *dist1, int *idx1, float *dist2, int *idx2) {
+  oracle_nnsearch(b, n, m, xyz1, xyz2, dist1, idx1);
+  oracle_nnsearch(b, m, n, xyz2, xyz1, dist2, idx2);
+}
+
+ORACLE_API void oracle_chamfer_backward(int b, int n, int m, const float *xyz1, const float *xyz2,
+                                        const float *gd1, const int *idx1, const float *gd2,
+                                        const int *idx2, float *g1, float *g2) {
+  for (size_t i = 0; i < (size_t)b * n * 3; ++i) g1[i] = 0;
+  for (size_t i = 0; i < (size_t)b * m * 3; ++i) g2[i] = 0;
+  for (int i = 0; i < b; ++i) {
+    for (int j = 0; j < n; ++j) {
+      const size_t a = ((size_t)i * n + j) * 3, c = ((size_t)i * m + idx1[(size_t)i * n + j]) * 3;
+      const float g = gd1[(size_t)i * n + j] * 2;
+      for (int d = 0; d < 3; ++d) {
+        const float t = g * (xyz1[a + d] - xyz2[c + d]);
+        g1[a + d] += t;
+        g2[c + d] -= t;
+      }
+    }
+    for (int j = 0; j < m; ++j) {
+      const size_t a = ((size_t)i * m + j) * 3, c = ((size_t)i * n + idx2[(size_t)i * m + j]) * 3;
+      const float g = gd2[(size_t)i * m + j] * 2;
+      for (int d = 0; d < 3; ++d) {
+        const float t = g * (xyz2[a + d] - xyz1[c + d]);
+        g2[a + d] += t;
+        g1[c + d] -= t;
+      }
+    }
+  }
+}

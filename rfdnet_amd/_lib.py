@@ -15,7 +15,7 @@ _f = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 _i = C.c_int
 _fl = C.c_float
 
-# name -> argtypes, exactly the prototypes of include/rfd_pointnet2.h / rfd_occ.h
+# name -> argtypes, exactly the prototypes of include/rfd_pointnet2.h / rfd_occ.h / rfd_chamfer.h
 SIGNATURES = {
     "furthest_point_sampling_kernel_wrapper": [_i, _i, _i, _f, _f, _f, _f],
     "gather_points_kernel_wrapper": [_i, _i, _i, _i, _f, _f, _f, _f],
@@ -28,6 +28,8 @@ SIGNATURES = {
     "three_interpolate_grad_kernel_wrapper": [_i, _i, _i, _i, _f, _f, _f, _f, _f],
     "rfd_group_concat": [_i, _i, _i, _i, _i, _fl, _i, _i, _f, _f, _f, _f, _f, _f, _f],
     "rfd_furthest_point_sampling_gather": [_i, _i, _i, _f, _f, _f, _f, _f],
+    "rfd_chamfer_forward": [_i, _i, _f, _i, _f, _f, _f, _f, _f, _f],
+    "rfd_chamfer_backward": [_i, _i, _f, _i, _f, _f, _f, _f, _f, _f, _f, _f],
     "rfd_sa_fused": [_i, _i, _i, _i, _i, _fl, _i, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f],
     "rfd_occ_pack_weights": [_f, _f, C.POINTER(C.c_int), _i, _f, _f],
     "rfd_occ_decode": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],

@@ -340,6 +340,41 @@ def make_nms():
     np.savez_compressed(os.path.join(HERE, "F_NMS.npz"), **out)
 
 
+def make_cd():
+    """F_CD: the reference's OWN CPU Chamfer op (chamfer_distance.cpp, built from the source
+    under /root/reference by oracle/build_ref_chamfer.py) on random clouds, an integer lattice
+    with many exact ties, and degenerate sizes: inputs + dist/idx both ways + gradients."""
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import build_ref_chamfer
+    cd = build_ref_chamfer.load()
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = [("rand", 2, 300, 517), ("lattice", 2, 256, 384), ("single", 1, 7, 1), ("big", 1, 1500, 4099)]
+    for name, B, n, m in cases:
+        if name == "lattice":
+            x1 = rng.integers(0, 4, (B, n, 3)).astype(np.float32)
+            x2 = rng.integers(0, 4, (B, m, 3)).astype(np.float32)
+        else:
+            x1 = rng.standard_normal((B, n, 3)).astype(np.float32)
+            x2 = (rng.standard_normal((B, m, 3)) * 1.3 + 0.2).astype(np.float32)
+        t1, t2 = torch.from_numpy(x1), torch.from_numpy(x2)
+        d1, d2 = torch.zeros(B, n), torch.zeros(B, m)
+        i1, i2 = torch.zeros(B, n, dtype=torch.int32), torch.zeros(B, m, dtype=torch.int32)
+        cd.forward(t1, t2, d1, d2, i1, i2)
+        g1 = rng.standard_normal((B, n)).astype(np.float32)
+        g2 = rng.standard_normal((B, m)).astype(np.float32)
+        gx1, gx2 = torch.zeros(B, n, 3), torch.zeros(B, m, 3)
+        cd.backward(t1, t2, gx1, gx2, torch.from_numpy(g1), torch.from_numpy(g2), i1, i2)
+        for k, v in (("x1", x1), ("x2", x2), ("d1", d1.numpy()), ("d2", d2.numpy()), ("i1", i1.numpy()),
+                     ("i2", i2.numpy()), ("g1", g1), ("g2", g2), ("gx1", gx1.numpy()), ("gx2", gx2.numpy())):
+            out["%s_%s" % (name, k)] = v
+        print("F_CD", name, B, n, m)
+    out["cases"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(HERE, "F_CD.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["dec", "mise", "grid"]
     for w in what:

@@ -88,6 +88,16 @@ def main():
     res["fps_sa1_onchip_GBps"] = 16.0 * 80000 * 2047 / res["fps_80000_2048_ms"] / 1e6
     res["ballq_sa1_Gtests_per_s_upper"] = 2048 * 80000 / res["ballq_sa1_ms"] / 1e6
     res["group_sa2_B32_frac_of_8TBps"] = res["group_sa2_B32_GBps"] / 8000.0
+    # Chamfer nearest-neighbour search at fit_mesh_to_scan sizes (network.py:194-195)
+    from rfdnet_amd import chamfer_distance as cdm
+    Bc, nc, mc = 16, 10000, 50000
+    a1 = torch.randn(Bc, nc, 3, device="cuda")
+    a2 = torch.randn(Bc, mc, 3, device="cuda")
+    t = timeit(lambda: cdm.nearest(a1, a2), warm=1, it=3)
+    res["chamfer_16x10000x50000_ms"] = t
+    res["chamfer_Gpairs_per_s"] = 2.0 * Bc * nc * mc / t / 1e6
+    res["chamfer_valu_TFLOPs_8flop_per_pair"] = 8 * 2.0 * Bc * nc * mc / t / 1e9
+    del a1, a2
     from rfdnet_amd import gemm
     for (M, N, K) in ((262144, 1024, 1024), (262144, 1024, 512), (262144, 512, 512)):
         xa = torch.randn(M, K, device="cuda")
