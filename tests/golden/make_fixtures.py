@@ -375,6 +375,100 @@ def make_cd():
     np.savez_compressed(os.path.join(HERE, "F_CD.npz"), **out)
 
 
+
+
+def make_fit():
+    """F_FIT: the reference's own ISCNet.fit_mesh_to_scan (network.py:182-303) run on CPU with
+    its Chamfer op = the reference's CPU implementation built from source (cd_ref), on a small
+    synthetic scene with three proposals (one filtered by the mask, two fitted).  100 Adam steps
+    over padded 10 000 x 50 000 point sets: takes several minutes."""
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import build_ref_chamfer
+    cd = build_ref_chamfer.load()
+
+    class _CD(torch.autograd.Function):           # glue only: calls the reference's CPU op
+        @staticmethod
+        def forward(ctx, a, b):
+            a, b = a.contiguous(), b.contiguous()
+            d1, d2 = torch.zeros(a.shape[0], a.shape[1]), torch.zeros(b.shape[0], b.shape[1])
+            i1 = torch.zeros(a.shape[0], a.shape[1], dtype=torch.int32)
+            i2 = torch.zeros(b.shape[0], b.shape[1], dtype=torch.int32)
+            cd.forward(a, b, d1, d2, i1, i2)
+            ctx.save_for_backward(a, b, i1, i2)
+            return d1, d2
+
+        @staticmethod
+        def backward(ctx, g1, g2):
+            a, b, i1, i2 = ctx.saved_tensors
+            ga, gb = torch.zeros_like(a), torch.zeros_like(b)
+            cd.backward(a, b, ga, gb, g1.contiguous(), g2.contiguous(), i1, i2)
+            return ga, gb
+
+    mount_reference()
+    tm = sys.modules['trimesh']
+    ex = ns('trimesh.exchange')
+    bx = ns('trimesh.exchange.binvox')
+    bx.voxelize_mesh = None
+    tm.exchange = ex
+    ex.binvox = bx
+    loss_shim = ns('models.loss')
+    loss_shim.chamfer_func = lambda a, b: _CD.apply(a, b)
+    net_mod = importlib.import_module('models.iscnet.modules.network')
+    from net_utils.box_util import get_3d_box
+    from net_utils.libs import flip_axis_to_camera
+
+    rng = np.random.default_rng(21)
+    # scene: floor + two box-shaped objects (surface samples, slightly noisy)
+    def box_surface(center, size, heading, npts):
+        u = rng.uniform(-0.5, 0.5, (npts, 3))
+        face = rng.integers(0, 3, npts)
+        u[np.arange(npts), face] = np.sign(rng.standard_normal(npts)) * 0.5
+        p = u * size
+        c, s = np.cos(heading), np.sin(heading)
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+        return p @ R.T + center
+    true_boxes = [((0.8, -0.5, 0.45), (1.2, 0.6, 0.9), 0.3), ((-1.1, 0.9, 0.35), (0.7, 0.7, 0.7), -0.6)]
+    floor = np.c_[rng.uniform(-3, 3, (6000, 2)), rng.normal(0, 0.005, 6000)]
+    scan = np.concatenate([floor] + [box_surface(np.array(c), np.array(s), h, 4000) for c, s, h in true_boxes])
+    scan = scan + rng.normal(0, 0.004, scan.shape)
+    scan = np.c_[scan, np.zeros(len(scan))].astype(np.float32)[None]            # (1,N,4)
+    # predictions: boxes a bit off the truth (what the fit has to correct); proposal 2 masked out
+    pred = [((0.9, -0.42, 0.45), (1.2, 0.6, 0.9), 0.42), ((-1.0, 0.98, 0.35), (0.7, 0.7, 0.7), -0.5),
+            ((2.0, 2.0, 0.5), (0.5, 0.5, 1.0), 0.0)]
+    K = len(pred)
+    corners = np.zeros((1, K, 8, 3))
+    for j, (c, s, h) in enumerate(pred):
+        corners[0, j] = get_3d_box(np.array(s), -h, flip_axis_to_camera(np.array(c)[None])[0])
+    obj_prob = np.array([[0.9, 0.8, 0.95]])
+    pred_mask = np.array([[1, 1, 0]])
+    parsed = {'pred_corners_3d_upright_camera': corners.copy(), 'pred_sem_cls': np.zeros((1, K), int),
+              'obj_prob': obj_prob}
+    # meshes: vertices of a unit-ish shape in the generator's canonical frame (any frame: the
+    # reference re-centres, permutes axes and normalises extents)
+    class M(object):
+        pass
+    meshes, verts = [], []
+    for j in range(K):
+        m = M()
+        m.vertices = box_surface(np.zeros(3), np.array([0.9, 1.0, 0.8]), 0.0, 1500 + 200 * j) + 0.03
+        meshes.append(m)
+        verts.append(m.vertices)
+    mesh_dict = {'meshes': meshes, 'proposal_ids': np.arange(K).reshape(1, K, 1)}
+    dummy = types.SimpleNamespace()
+    dummy.chamfer_dist = lambda *a: net_mod.ISCNet.chamfer_dist(dummy, *a)
+    out = net_mod.ISCNet.fit_mesh_to_scan(dummy, mesh_dict, parsed, {'pred_mask': pred_mask},
+                                           torch.from_numpy(scan), 0.5)
+    fitted = out['pred_corners_3d_upright_camera']
+    print("F_FIT corner shift (max abs):", np.abs(fitted - corners).reshape(K, -1).max(1))
+    sav = {'scan': scan, 'corners_in': corners, 'corners_out': fitted, 'obj_prob': obj_prob,
+           'pred_mask': pred_mask, 'n_meshes': np.array(K)}
+    for j in range(K):
+        sav['verts_%d' % j] = verts[j]
+    np.savez_compressed(os.path.join(HERE, "F_FIT.npz"), **sav)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["dec", "mise", "grid"]
     for w in what:
