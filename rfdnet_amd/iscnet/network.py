@@ -120,6 +120,13 @@ class ISCNet(nn.Module):
         return one_hot.view(-1, sem.size(2))
 
     @torch.no_grad()
+    def fit_mesh_to_scan(self, pred_mesh_dict, parsed_predictions, eval_dict, input_scan, dump_threshold):
+        """Box refinement of the evaluation path (network.py:182-303); see iscnet/fit.py.
+        pred_mesh_dict = {'meshes': [...], 'proposal_ids': (B,K',1)} as in the reference."""
+        from . import fit
+        return fit.fit_mesh_to_scan(pred_mesh_dict['meshes'], pred_mesh_dict['proposal_ids'], parsed_predictions,
+                                    eval_dict, input_scan, dump_threshold)
+
     def generate(self, data, selection='all', return_grids=False):
         """data['point_clouds'] (B,N,3+f) -> (end_points, proposal ids, meshes)."""
         pc = data['point_clouds']
