@@ -1,34 +1,49 @@
-"""Hough voting head (models/iscnet/modules/vote_module.py:12-61): three 1x1
-convolutions produce a 3-D offset and a feature residual per seed."""
+"""Hough voting head: every seed casts `vote_factor` votes = its position plus a learnt offset,
+carrying its feature plus a learnt residual (models/iscnet/modules/vote_module.py:12-61).
+
+Parameter names (conv1..3, bn1..2) are the reference's, so its checkpoints load.  The head's
+last convolution emits, per vote v, the block [offset(3) | residual(256)] at channels
+v*(3+256)..; the outputs are assembled channel-major directly, without the reference's two
+transposes of the (B, S, vf, 259) tensor."""
 import torch
-import torch.nn.functional as F
+from torch import nn
 
 from .registers import MODULES
 
+SEED_FEATURE_DIM = 256
+
+
+def _head(module, widths, d_in):
+    """conv{i} for every layer, then bn{i} for all but the last, as attributes of `module`
+    (registration order = the reference's state_dict order: all convolutions first)."""
+    for i, w in enumerate(widths, start=1):
+        setattr(module, 'conv%d' % i, nn.Conv1d(d_in, w, kernel_size=1))
+        d_in = w
+    for i, w in enumerate(widths[:-1], start=1):
+        setattr(module, 'bn%d' % i, nn.BatchNorm1d(w))
+
 
 @MODULES.register_module
-class VotingModule(torch.nn.Module):
+class VotingModule(nn.Module):
     def __init__(self, cfg, optim_spec=None):
         super().__init__()
-        self.optim_spec = optim_spec
-        self.vote_factor = cfg.config['data']['vote_factor']
-        self.in_dim = 256
-        self.out_dim = self.in_dim            # residual features: in == out
-        self.conv1 = torch.nn.Conv1d(self.in_dim, self.in_dim, 1)
-        self.conv2 = torch.nn.Conv1d(self.in_dim, self.in_dim, 1)
-        self.conv3 = torch.nn.Conv1d(self.in_dim, (3 + self.out_dim) * self.vote_factor, 1)
-        self.bn1 = torch.nn.BatchNorm1d(self.in_dim)
-        self.bn2 = torch.nn.BatchNorm1d(self.in_dim)
+        self.optim_spec = optim_spec                      # only read by the (out-of-scope) trainer
+        self.vote_factor = int(cfg.config['data']['vote_factor'])
+        d = SEED_FEATURE_DIM
+        self.in_dim = self.out_dim = d                     # residual connection: widths must agree
+        _head(self, (d, d, (3 + d) * self.vote_factor), d)
 
     def forward(self, seed_xyz, seed_features):
-        """seed_xyz (B,S,3), seed_features (B,256,S) ->
-        vote_xyz (B,S*vf,3), vote_features (B,256,S*vf)."""
-        B, S = seed_xyz.shape[0], seed_xyz.shape[1]
-        vf = self.vote_factor
-        net = F.relu(self.bn1(self.conv1(seed_features)))
-        net = F.relu(self.bn2(self.conv2(net)))
-        net = self.conv3(net).transpose(2, 1).view(B, S, vf, 3 + self.out_dim)
-        vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).contiguous().view(B, S * vf, 3)
-        vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]
-        vote_features = vote_features.contiguous().view(B, S * vf, self.out_dim)
-        return vote_xyz, vote_features.transpose(2, 1).contiguous()
+        """seed_xyz (B,S,3), seed_features (B,256,S) -> vote_xyz (B,S*vf,3), vote_features
+        (B,256,S*vf); vote s*vf + v belongs to seed s."""
+        B, S, _ = seed_xyz.shape
+        vf, d = self.vote_factor, self.out_dim
+        h = seed_features
+        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2)):
+            h = torch.relu(bn(conv(h)))
+        out = self.conv3(h).view(B, vf, 3 + d, S)                       # [vote][offset | residual][seed]
+        offsets = out[:, :, :3].permute(0, 3, 1, 2)                      # (B,S,vf,3)
+        vote_xyz = (seed_xyz.unsqueeze(2) + offsets).reshape(B, S * vf, 3)
+        feats = seed_features.unsqueeze(1) + out[:, :, 3:]               # (B,vf,d,S)
+        vote_features = feats.permute(0, 2, 3, 1).reshape(B, d, S * vf)
+        return vote_xyz, vote_features
