@@ -1,38 +1,34 @@
-"""Name -> class registries with the reference's registry names and keys
-(models/registers.py:5-9, net_utils/registry.py:6-47): the YAML `model:` block
-selects sub-networks by `method` name through MODULES.get(name)(cfg, optim_spec)
-(models/iscnet/modules/network.py:40-47)."""
-import inspect
+"""Name -> class tables for the sub-networks the YAML `model:` block selects by `method`
+(reference: models/registers.py:5-9, net_utils/registry.py:6-47; used as
+`MODULES.get(name)(cfg, optim_spec)`, models/iscnet/modules/network.py:40-47).
+
+A table is a dict subclass keyed by class name: `@TABLE.register_module` adds a class (and
+refuses duplicates and non-classes), `TABLE.get(key, alter_key)` falls back to a second key."""
 
 
-class Registry(object):
+class Registry(dict):
     def __init__(self, name):
-        self._name = name
-        self._module_dict = {}
-
-    def __repr__(self):
-        return "%s(name=%s, items=%s)" % (type(self).__name__, self._name, list(self._module_dict))
-
-    @property
-    def name(self):
-        return self._name
+        super().__init__()
+        self.name = name
 
     @property
     def module_dict(self):
-        return self._module_dict
+        return self
 
-    def get(self, key, alter_key=None):
-        if key in self._module_dict:
-            return self._module_dict[key]
-        return self._module_dict.get(alter_key, None)
+    def get(self, key, alter_key=None):              # noqa: A003 (dict.get with a fallback KEY)
+        found = dict.get(self, key)
+        return found if found is not None else dict.get(self, alter_key)
 
     def register_module(self, cls):
-        if not inspect.isclass(cls):
-            raise TypeError("module must be a class, but got %s" % type(cls))
-        if cls.__name__ in self._module_dict:
-            raise KeyError("%s is already registered in %s" % (cls.__name__, self._name))
-        self._module_dict[cls.__name__] = cls
+        if not isinstance(cls, type):
+            raise TypeError("only classes can be registered in %r, got %s" % (self.name, type(cls).__name__))
+        if cls.__name__ in self:
+            raise KeyError("%r already holds a class named %s" % (self.name, cls.__name__))
+        self[cls.__name__] = cls
         return cls
+
+    def __repr__(self):
+        return "Registry(%s: %s)" % (self.name, ", ".join(sorted(self)))
 
 
 METHODS = Registry('method')
