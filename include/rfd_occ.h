@@ -170,13 +170,16 @@ int rfd_nms3d(int b, int K, double iou_thr, int old_type, int use_cls, const dou
  * optional ReLU on A and on C; three f16 MFMAs per product on (hi, lo) operand splits.
  * Replaces the fp32 GEMMs of the skip-propagation encoder (layers.py:340-392).
  * W is re-laid once with rfd_gemm_pack_w (scaled by 2^sw); A is scaled by 2^sa on the fly.
- * M % 128 == N % 128 == K % 32 == 0, lda % 4 == 0. */
+ * M % 128 == N % 128 == K % 32 == 0, lda % 4 == 0.
+ * pool_max (optional, [M / rows_per_group][N], zero-initialised by the caller): running
+ * max(0, C) over the rows of each group = the encoder's max-pool + ReLU (layers.py:380-392)
+ * fused into the epilogue; needs the row-owner kernel (M, N % 256, K % 128, rows_per_group % 64). */
 size_t rfd_gemm_packed_bytes(int N, int K);
 int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, void *stream);
 int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *packed_w,
                    float *C, int ldc, const float *bias, const float *gbias,
                    int rows_per_group, const float *R, int ldr, int relu_in, int relu_out,
-                   int sa, int sw, void *stream);
+                   int sa, int sw, float *pool_max, void *stream);
 
 /* ---- one ResnetBlockFC of the point encoder, fused (csrc/resblock.hip) ----------------
  * Replaces ResnetBlockFC.forward (models/iscnet/modules/layers.py:39-48) inside

@@ -43,7 +43,7 @@ SIGNATURES = {
     "rfd_points_in_boxes": [_i, _i, _i, _i, _f, _f, _f, _f],
     "rfd_nms3d": [_i, _i, C.c_double, _i, _i, _f, _f, _f, _f, _f, _f],
     "rfd_gemm_pack_w": [_i, _i, _i, _f, _f, _f],
-    "rfd_gemm_f16x3": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _i, _i, _i, _f],
+    "rfd_gemm_f16x3": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _i, _i, _i, _f, _f],
     "rfd_resblock_pack": [_i, _i, _f, _f, _f, _i, _i, _f, _f],
     "rfd_resblock_f16x3": [_i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _f],
     "rfd_mc_classify": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f],

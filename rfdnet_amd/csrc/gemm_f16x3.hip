@@ -72,10 +72,12 @@ struct Args {
   float *C; int ldc;
   const float *bias;            // [N] or null
   const float *gbias; int rows_per_group;  // [M/rpg][N] or null
+  int gbias_stride;                        // N, or 0 when gbias is the zero vector (row-owner kernel)
   const float *R; int ldr;      // [M][ldr] or null
   int M, N, K;
   int relu_in, relu_out;
   float a_scale, out_scale;     // 2^sa, 2^-(sa+sw)
+  float *pool;                  // [M/rows_per_group][N] running max(0, C) per group, or null (row-owner kernel)
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(512) void gemm_rows8_kernel(Args g) {
   {
     float *tr = reinterpret_cast<float *>(smem + wave * 16384);
     const int l = lane & 31, rsel = lane >> 5;
-    const float *grow = g.gbias + (size_t)(m0 / g.rows_per_group) * g.N + n0 + 4 * l;
+    const float *grow = g.gbias + (size_t)(m0 / g.rows_per_group) * g.gbias_stride + n0 + 4 * l;
     const float *brow = g.bias + n0 + 4 * l;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -424,6 +426,7 @@ __global__ __launch_bounds__(512) void gemm_rows8_kernel(Args g) {
           for (int e = 0; e < 4; ++e) v[e] = acc[4 * p + bb][4 * q + e];
           *reinterpret_cast<f32x4 *>(tr + n * 128 + ((chunk ^ n) * 4)) = v;
         }
+      f32x4 pmax = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
       for (int j = 0; j < 16; ++j) {
         const int row = 2 * j + rsel;
@@ -436,8 +439,20 @@ __global__ __launch_bounds__(512) void gemm_rows8_kernel(Args g) {
         for (int e = 0; e < 4; ++e) {
           o[e] = __builtin_fmaf(a[e], g.out_scale, add[e]);
           if (g.relu_out) o[e] = o[e] > 0.f ? o[e] : 0.f;
+          pmax[e] = o[e] > pmax[e] ? o[e] : pmax[e];
         }
         *reinterpret_cast<f32x4 *>(g.C + m * g.ldc + n0 + 128 * p + 4 * l) = o;
+      }
+      if (g.pool) {
+        // fused max-pool over the group's rows (every consumer rectifies the pooled vector, so
+        // max(0, .) is what is needed): non-negative floats order like their bit patterns
+        int *pp = reinterpret_cast<int *>(g.pool + (size_t)(m0 / g.rows_per_group) * g.N + n0 + 128 * p + 4 * l);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float other = __shfl_xor(pmax[e], 32);
+          const float v = other > pmax[e] ? other : pmax[e];
+          if (rsel == 0 && v > 0.f) atomicMax(pp + e, __float_as_int(v));
+        }
       }
     }
   }
@@ -469,7 +484,7 @@ RFD_API int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, 
 RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *packed_w,
                            float *C, int ldc, const float *bias, const float *gbias,
                            int rows_per_group, const float *R, int ldr, int relu_in, int relu_out,
-                           int sa, int sw, void *stream) {
+                           int sa, int sw, float *pool_max, void *stream) {
   if (M <= 0) return 0;
   if (M % BM || N % BN || K % BK || (lda & 3)) {
     rfd_set_error("rfd_gemm_f16x3: shape not a multiple of the 128x128x32 tile", hipErrorInvalidValue);
@@ -480,17 +495,19 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
   g.gbias = gbias; g.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; g.R = R; g.ldr = ldr;
   g.M = M; g.N = N; g.K = K; g.relu_in = relu_in; g.relu_out = relu_out;
   g.a_scale = ldexpf(1.f, sa); g.out_scale = ldexpf(1.f, -(sa + sw));
+  g.pool = pool_max;
+  g.gbias_stride = N;
   const bool aligned = !(ldc & 3) && !(ldr & 3) && !((uintptr_t)C & 15) && !((uintptr_t)R & 15) &&
                        !((uintptr_t)bias & 15) && !((uintptr_t)gbias & 15);
   if (M % RM == 0 && N % RN == 0 && N <= RFD_ZEROS_FLOATS && K % 128 == 0 && aligned &&
-      (!gbias || g.rows_per_group % 64 == 0) && getenv("RFD_GEMM_TILE_ONLY") == nullptr) {
+      ((!gbias && !pool_max) || g.rows_per_group % 64 == 0) && getenv("RFD_GEMM_TILE_ONLY") == nullptr) {
     RfdWorkspace *ws;
     int rc = rfd_get_workspace(&ws);
     if (rc) return rc;
     if (!g.bias) g.bias = ws->zeros;
     if (!g.gbias) {
-      g.gbias = ws->zeros;
-      g.rows_per_group = M;      // every row reads group 0
+      g.gbias = ws->zeros;       // every group reads the same zero vector
+      g.gbias_stride = 0;
     }
     const dim3 grid((M / RM) * (N / RN));
     hipStream_t s = (hipStream_t)stream;
@@ -499,6 +516,11 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
     else if (R) hipLaunchKernelGGL((gemm_rows8_kernel<false, true>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((gemm_rows8_kernel<false, false>), grid, dim3(512), 0, s, g);
   } else {
+    if (pool_max) {
+      rfd_set_error("rfd_gemm_f16x3: pool_max needs the row-owner kernel (M, N % 256, K % 128, "
+                    "rows_per_group % 64, 16-byte aligned operands)", hipErrorInvalidValue);
+      return (int)hipErrorInvalidValue;
+    }
     hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, (hipStream_t)stream, g);
   }
   RFD_CHECK_LAUNCH();

@@ -40,8 +40,10 @@ def _packed(weight):
 
 
 def linear(x, weight, bias=None, gbias=None, rows_per_group=1, residual=None, relu_in=False,
-           relu_out=False, out=None):
-    """x (M,K) fp32 rows (row stride >= K allowed), weight (N,K) -> (M,N)."""
+           relu_out=False, out=None, pool=None):
+    """x (M,K) fp32 rows (row stride >= K allowed), weight (N,K) -> (M,N).
+    pool: optional (M / rows_per_group, N) ZERO-initialised tensor that receives
+    max(0, out) over the rows of every group (fused max-pool + ReLU)."""
     M, K = x.shape
     N = weight.shape[0]
     assert usable(M, N, K, x)
@@ -55,6 +57,11 @@ def linear(x, weight, bias=None, gbias=None, rows_per_group=1, residual=None, re
             bias.data_ptr() if bias is not None else None,
             gbias.data_ptr() if gbias is not None else None, int(rows_per_group),
             residual.data_ptr() if residual is not None else None, ldr,
-            int(relu_in), int(relu_out), SA, sw, _lib.current_stream())
+            int(relu_in), int(relu_out), SA, sw, pool.data_ptr() if pool is not None else None,
+            _lib.current_stream())
     _lib.check(rc, "rfd_gemm_f16x3")
     return out
+
+
+def pool_usable(M, N, K, rows_per_group):
+    return M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and rows_per_group % 64 == 0

@@ -97,24 +97,37 @@ class ResnetPointnet(nn.Module):
 
         # block 0: both halves of its 2h-wide input are per-point
         blk, (_, _, _, bias0, w_full) = stacked(0)
+        # the max-pool over a proposal's points (+ the ReLU every consumer applies to it) rides in
+        # the epilogue of each block's second GEMM
+        fuse_pool = fast and gemm.pool_usable(B * T, h, h, T)
+
+        def second(blk, both):
+            pooled = torch.zeros(B, h, device=both.device, dtype=both.dtype) if fuse_pool else None
+            out = gemm.linear(both[:, :h], blk.fc_1.weight, bias=blk.fc_1.bias, residual=both[:, h:],
+                              relu_in=True, rows_per_group=T, pool=pooled)
+            return out.view(B, T, h), pooled
+
+        pooled = None
         if fast:
             x2 = pos_term.view(B * T, 2 * h)
             both = gemm.linear(x2, w_full, bias=bias0, relu_in=True)                       # (M,2h)
-            net = gemm.linear(both[:, :h], blk.fc_1.weight, bias=blk.fc_1.bias, residual=both[:, h:],
-                              relu_in=True).view(B, T, h)
+            net, pooled = second(blk, both)
         else:
             net = self.block_0(pos_term)
         for i in range(1, 5):
             blk, (_, w_pt, w_pl, bias, _) = stacked(i)
-            pooled = torch.relu(self.pool(net, dim=1))                       # (B,h)
+            if pooled is None:
+                pooled = torch.relu(self.pool(net, dim=1))                   # (B,h)
             gb = F.linear(pooled, w_pl, bias)                                # (B,2h): once per proposal
+            pooled = None
             if fast:
                 both = gemm.linear(net.view(B * T, h), w_pt, gbias=gb, rows_per_group=T, relu_in=True)
-                net = gemm.linear(both[:, :h], blk.fc_1.weight, bias=blk.fc_1.bias, residual=both[:, h:],
-                                  relu_in=True).view(B, T, h)
+                net, pooled = second(blk, both)
             else:
                 both = F.linear(torch.relu(net), w_pt) + gb.unsqueeze(1)     # (B,T,2h)
                 dx = blk.fc_1(torch.relu(both[..., :h]))
                 net = both[..., h:] + dx
+        if pooled is not None:                                               # = relu(max over the points)
+            return self.fc_c(pooled)
         net = self.pool(net, dim=1)
         return self.fc_c(self.actvn(net))

@@ -72,3 +72,24 @@ def test_resnet_pointnet_fast_path_equals_plain(hip):
         plain = enc(x)
         fast = enc.forward_factored(enc.fc_pos(x))
     assert (plain - fast).abs().max().item() < 1e-4 * max(1.0, plain.abs().max().item())
+
+
+def test_fused_group_max_pool(hip):
+    """pool = max(0, C) over the rows of each group, from the epilogue of the row-owner kernel."""
+    from rfdnet_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(7)
+    M, N, K, T = 1024, 512, 256, 128
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.1
+    bias = torch.randn(N, device="cuda", generator=g) - 1.0          # some columns stay negative everywhere
+    res = torch.randn(M, N, device="cuda", generator=g)
+    pool = torch.zeros(M // T, N, device="cuda")
+    y = gemm.linear(x, w, bias=bias, residual=res, relu_in=True, rows_per_group=T, pool=pool)
+    want = torch.relu(y.view(M // T, T, N).max(dim=1)[0])
+    assert torch.equal(pool, want)
+    r = ref(x, w, bias, None, 1, res, True, False)
+    assert (y.double() - r).abs().max().item() < 2e-5 * max(1.0, r.abs().max().item())
+    # shapes that only the tile kernel takes cannot pool: an error, not a silent skip
+    with pytest.raises(Exception):
+        gemm.linear(x[:, :96].contiguous(), w[:, :96].contiguous(), rows_per_group=T,
+                    pool=torch.zeros(M // T, N, device="cuda"))
