@@ -173,7 +173,8 @@ int rfd_nms3d(int b, int K, double iou_thr, int old_type, int use_cls, const dou
  * M % 128 == N % 128 == K % 32 == 0, lda % 4 == 0.
  * pool_max (optional, [M / rows_per_group][N], zero-initialised by the caller): running
  * max(0, C) over the rows of each group = the encoder's max-pool + ReLU (layers.py:380-392)
- * fused into the epilogue; needs the row-owner kernel (M, N % 256, K % 128, rows_per_group % 64). */
+ * fused into the epilogue; needs the row-owner kernel (M, N % 256, K % 128, rows_per_group % 64).
+ * With pool_max, C may be NULL: the product is then only pooled, never written. */
 size_t rfd_gemm_packed_bytes(int N, int K);
 int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, void *stream);
 int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *packed_w,

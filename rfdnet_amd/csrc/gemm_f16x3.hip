@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512) void gemm_rows8_kernel(Args g) {
           if (g.relu_out) o[e] = o[e] > 0.f ? o[e] : 0.f;
           pmax[e] = o[e] > pmax[e] ? o[e] : pmax[e];
         }
-        *reinterpret_cast<f32x4 *>(g.C + m * g.ldc + n0 + 128 * p + 4 * l) = o;
+        if (g.C) *reinterpret_cast<f32x4 *>(g.C + m * g.ldc + n0 + 128 * p + 4 * l) = o;   // C may be omitted when only the pool is wanted
       }
       if (g.pool) {
         // fused max-pool over the group's rows (every consumer rectifies the pooled vector, so
@@ -486,6 +486,10 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
                            int rows_per_group, const float *R, int ldr, int relu_in, int relu_out,
                            int sa, int sw, float *pool_max, void *stream) {
   if (M <= 0) return 0;
+  if (!C && !pool_max) {
+    rfd_set_error("rfd_gemm_f16x3: C == NULL without pool_max", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
   if (M % BM || N % BN || K % BK || (lda & 3)) {
     rfd_set_error("rfd_gemm_f16x3: shape not a multiple of the 128x128x32 tile", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
@@ -516,8 +520,8 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
     else if (R) hipLaunchKernelGGL((gemm_rows8_kernel<false, true>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((gemm_rows8_kernel<false, false>), grid, dim3(512), 0, s, g);
   } else {
-    if (pool_max) {
-      rfd_set_error("rfd_gemm_f16x3: pool_max needs the row-owner kernel (M, N % 256, K % 128, "
+    if (pool_max || !C) {
+      rfd_set_error("rfd_gemm_f16x3: pool_max / C == NULL need the row-owner kernel (M, N % 256, K % 128, "
                     "rows_per_group % 64, 16-byte aligned operands)", hipErrorInvalidValue);
       return (int)hipErrorInvalidValue;
     }

@@ -40,20 +40,25 @@ def _packed(weight):
 
 
 def linear(x, weight, bias=None, gbias=None, rows_per_group=1, residual=None, relu_in=False,
-           relu_out=False, out=None, pool=None):
+           relu_out=False, out=None, pool=None, store=True):
     """x (M,K) fp32 rows (row stride >= K allowed), weight (N,K) -> (M,N).
     pool: optional (M / rows_per_group, N) ZERO-initialised tensor that receives
-    max(0, out) over the rows of every group (fused max-pool + ReLU)."""
+    max(0, out) over the rows of every group (fused max-pool + ReLU); with store=False the
+    product itself is not written (returns None)."""
     M, K = x.shape
     N = weight.shape[0]
     assert usable(M, N, K, x)
     packed, sw, _ = _packed(weight)
-    if out is None:
+    if store is False:
+        assert pool is not None, "store=False only makes sense with a pool"
+        out = None
+    elif out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     ldr = residual.stride(0) if residual is not None else 0
     with torch.cuda.device(x.device):
         rc = _lib.lib().rfd_gemm_f16x3(
-            M, N, K, x.data_ptr(), x.stride(0), packed.data_ptr(), out.data_ptr(), out.stride(0),
+            M, N, K, x.data_ptr(), x.stride(0), packed.data_ptr(),
+            out.data_ptr() if out is not None else None, out.stride(0) if out is not None else N,
             bias.data_ptr() if bias is not None else None,
             gbias.data_ptr() if gbias is not None else None, int(rows_per_group),
             residual.data_ptr() if residual is not None else None, ldr,

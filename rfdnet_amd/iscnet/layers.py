@@ -101,11 +101,12 @@ class ResnetPointnet(nn.Module):
         # the epilogue of each block's second GEMM
         fuse_pool = fast and gemm.pool_usable(B * T, h, h, T)
 
-        def second(blk, both):
+        def second(blk, both, last=False):
             pooled = torch.zeros(B, h, device=both.device, dtype=both.dtype) if fuse_pool else None
             out = gemm.linear(both[:, :h], blk.fc_1.weight, bias=blk.fc_1.bias, residual=both[:, h:],
-                              relu_in=True, rows_per_group=T, pool=pooled)
-            return out.view(B, T, h), pooled
+                              relu_in=True, rows_per_group=T, pool=pooled,
+                              store=not (last and fuse_pool))      # the last block is only pooled
+            return (out.view(B, T, h) if out is not None else None), pooled
 
         pooled = None
         if fast:
@@ -122,7 +123,7 @@ class ResnetPointnet(nn.Module):
             pooled = None
             if fast:
                 both = gemm.linear(net.view(B * T, h), w_pt, gbias=gb, rows_per_group=T, relu_in=True)
-                net, pooled = second(blk, both)
+                net, pooled = second(blk, both, last=(i == 4))
             else:
                 both = F.linear(torch.relu(net), w_pt) + gb.unsqueeze(1)     # (B,T,2h)
                 dx = blk.fc_1(torch.relu(both[..., :h]))

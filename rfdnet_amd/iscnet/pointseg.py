@@ -41,11 +41,10 @@ class _TNet(nn.Module):
     def forward_rows(self, x, P):
         """Row-major inference path: x (B*P, k_in) -> (B, k_out, k_out).  BN folded,
         the wide layers on the split-precision GEMM with fused bias + ReLU."""
-        from ..fold_bn import folded, linear_rows
+        from ..fold_bn import folded, linear_rows, linear_rows_pooled
         h = linear_rows(x, *folded(self.conv1, self.bn1), relu=True)
         h = linear_rows(h, *folded(self.conv2, self.bn2), relu=True)
-        h = linear_rows(h, *folded(self.conv3, self.bn3), relu=True)
-        g = h.view(-1, P, h.shape[1]).max(dim=1)[0]
+        g = linear_rows_pooled(h, *folded(self.conv3, self.bn3), rows_per_group=P)    # relu + max over the points
         g = linear_rows(g, *folded(self.fc1, self.bn4), relu=True)
         g = linear_rows(g, *folded(self.fc2, self.bn5), relu=True)
         g = F.linear(g, self.fc3.weight, self.fc3.bias)
