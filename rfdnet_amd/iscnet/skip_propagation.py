@@ -50,6 +50,7 @@ class SkipPropagation(nn.Module):
         d = inp.shape[2]
         box = box_feature.transpose(1, 2).contiguous().view(B * K, -1)          # (B*K,128)
         w = enc.fc_pos.weight
-        pos = F.linear(inp * maskf, w[:, :d], enc.fc_pos.bias) + maskf * F.linear(box, w[:, d:]).unsqueeze(1)
+        pos = F.linear(inp * maskf, w[:, :d], enc.fc_pos.bias)                  # (B*K,P,2h)
+        pos.addcmul_(maskf, F.linear(box, w[:, d:]).unsqueeze(1))               # one pass instead of mul + add
         codes = enc.forward_factored(pos)
         return codes.view(B, K, -1).transpose(1, 2)
