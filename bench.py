@@ -366,7 +366,9 @@ def main():
                        "scenes_per_step": S * NB * world,
                        "parallelism": "scenes sharded across GPUs, dp%d; %d forward passes of %d scene(s) in flight per GPU"
                                       % (world, S, NB)},
-            "roofline": {"bound": "mfma", "kernel": "occ_decode_kernel<%d>" % (3 if args.mode == "f16x3" else 1),
+            "roofline": {"bound": "mfma",
+                         "kernel": "%s<%d>" % ("occ_decode8_kernel" if nets[0].completion.decoder.kernel == "w8"
+                                               else "occ_decode_kernel", 3 if args.mode == "f16x3" else 1),
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_PEAK_TFLOPS,
                          # HBM bytes per launch: the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate

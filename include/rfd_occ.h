@@ -165,6 +165,15 @@ int rfd_nms3d(int b, int K, double iou_thr, int old_type, int use_cls, const dou
               const int *order, const int *cls, const unsigned char *valid,
               unsigned char *keep, void *stream);
 
+/* Eight-wave variant of the fused decoder (csrc/occ_decoder8.hip): same arguments, results and
+ * table as rfd_occ_decode; its weight stream has a different fragment order (16x16x32 MFMA) and
+ * is produced by rfd_occ_pack_weights_w8 into a buffer of rfd_occ_packed_bytes() bytes. */
+int rfd_occ_pack_weights_w8(const float *fc0_w, const float *fc1_w, const int *kw0, int kw1,
+                            void *packed, void *stream);
+int rfd_occ_decode_w8(int n_tiles, const float *pts, const int *tile_prop, const int *tile_src,
+                      const void *packed, const float *fc_p_w, const float *table,
+                      const float *fc_out_w, float fc_out_b, float *logits, int mode, void *stream);
+
 /* ---- fp32-class GEMM on the f16 matrix cores (csrc/gemm_f16x3.hip) -----------------
  * C[M,N] = act(A)[M,K] . W[N,K]^T (+ bias[N]) (+ gbias[m / rows_per_group][N]) (+ R[M,N]),
  * optional ReLU on A and on C; three f16 MFMAs per product on (hi, lo) operand splits.

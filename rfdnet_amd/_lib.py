@@ -33,6 +33,8 @@ SIGNATURES = {
     "rfd_sa_fused": [_i, _i, _i, _i, _i, _fl, _i, _f, _f, _f, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f],
     "rfd_occ_pack_weights": [_f, _f, C.POINTER(C.c_int), _i, _f, _f],
     "rfd_occ_decode": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],
+    "rfd_occ_pack_weights_w8": [_f, _f, C.POINTER(C.c_int), _i, _f, _f],
+    "rfd_occ_decode_w8": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],
     "rfd_make_grid_points": [_i, _fl, _fl, _fl, _f, _i, _f],
     "rfd_mise_init": [_i, _i, _i, _f, _f, _f],
     "rfd_mise_count": [_i, _i, _i, _f, _f, _f],

@@ -1,0 +1,357 @@
+// occ_decoder8.hip -- the fused occupancy decoder (see occ_decoder.hip for the network, the
+// folding and the arithmetic) with EIGHT waves per workgroup.
+//
+// Same 128-point tile and the same LDS weight ring, but a wave owns 16 points x all 256
+// channels and uses v_mfma_f32_16x16x32_f16: the residual stream is 16 tiles x 4 accumulator
+// registers, the block input 8 k-steps x (hi, lo) fragments -- about 220 registers, so TWO waves
+// share each SIMD.  While one of them is stuck issuing an LDS-DMA transfer, parked at a wait /
+// barrier or doing epilogue arithmetic, the other keeps the matrix pipe busy; the 4-wave kernel
+// (one 496-register wave per SIMD) has nobody to fill those slots.
+//
+// Layouts (16x16x32): A fragment = lane (m = lane & 15, kg = lane >> 4) holds k = 8 kg + j of
+// output channel m; B fragment = lane (n = lane & 15, kg) holds k = 8 kg + j of point n;
+// D = lane (n, g = lane >> 4) holds channels 4 g + r of a 16-channel tile.  A 32-wide k-step
+// covers channel tiles 2 ks and 2 ks + 1, and lane (n, g) feeds its own accumulators back:
+// slot j < 4 = tile 2 ks, channel 4 g + j; j >= 4 = tile 2 ks + 1, channel 4 g + (j - 4).  The
+// pack kernel orders every weight matrix's columns accordingly, so activations never leave
+// the lane (as in the 4-wave kernel).
+#include "common.h"
+#include "../../include/rfd_occ.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int H = RFD_OCC_HIDDEN;
+constexpr int NB = RFD_OCC_BLOCKS;
+constexpr int TILE = RFD_OCC_TILE;
+constexpr int ROWS = RFD_OCC_TABLE_ROWS;
+constexpr int FRAG_HALVES = 64 * 8;
+constexpr size_t PACKED_HALVES = (size_t)NB * 8 * 64 * FRAG_HALVES;     // same size as the 4-wave stream
+constexpr int SMEM_TAB_BYTES = (ROWS * H + H * 3 + H) * 4;
+constexpr int HALF_FRAGS = 32;
+constexpr int HALF_BYTES = HALF_FRAGS * FRAG_HALVES * 2;                  // 32 KiB
+constexpr int N_HALVES = NB * 8 * 2;
+constexpr int SMEM_BYTES = SMEM_TAB_BYTES + 4 * HALF_BYTES;
+
+// Stream order = consumption order.  Chunk (blk, mb):
+//   fragments  0..31 : fc_0 rows of block mb (tiles 2mb, 2mb+1): q = 4 ks + 2 tt + s
+//   fragments 32..63 : fc_1 columns of slab mb (k-step mb) for the 16 output tiles: q = 2 t + s
+// in_ch(ks, kg, j) = 32 ks + 16 (j >> 2) + 4 kg + (j & 3).
+__global__ void pack8_kernel(const float *__restrict__ fc0_w, const float *__restrict__ fc1_w, int kw0_0,
+                             int kw0_1, int kw0_2, int kw0_3, int kw0_4, int kw1,
+                             _Float16 *__restrict__ packed) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= PACKED_HALVES) return;
+  const int j = e & 7;
+  const int lane = (e >> 3) & 63;
+  const int frag = (int)(e >> 9);
+  const int q = frag & 31;
+  const int second = (frag >> 5) & 1;
+  const int mb = (frag >> 6) & 7;
+  const int blk = frag >> 9;
+  const int m = lane & 15, kg = lane >> 4;
+  const int s = q & 1;
+  int out_ch, in_ch, kw;
+  const float *W;
+  if (!second) {
+    const int ks = q >> 2, tt = (q >> 1) & 1;
+    out_ch = 32 * mb + 16 * tt + m;
+    in_ch = 32 * ks + 16 * (j >> 2) + 4 * kg + (j & 3);
+    W = fc0_w + (size_t)blk * H * H;
+    kw = blk == 0 ? kw0_0 : blk == 1 ? kw0_1 : blk == 2 ? kw0_2 : blk == 3 ? kw0_3 : kw0_4;
+  } else {
+    const int t = q >> 1;
+    out_ch = 16 * t + m;
+    in_ch = 32 * mb + 16 * (j >> 2) + 4 * kg + (j & 3);
+    W = fc1_w + (size_t)blk * H * H;
+    kw = kw1;
+  }
+  const float w = ldexpf(W[(size_t)out_ch * H + in_ch], kw);
+  const _Float16 hi = (_Float16)w;
+  const _Float16 lo = (_Float16)(w - (float)hi);
+  packed[e] = s == 0 ? hi : lo;
+}
+
+__device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// relu(s x + t) of two values -> packed f16 hi (round to zero) and lo words
+template <bool WITH_LO>
+__device__ __forceinline__ void act2(float x0, float x1, float s0, float s1, float t0, float t1, unsigned &hiw,
+                                     unsigned &low, unsigned &amax16) {
+  float a0 = __builtin_fmaf(s0, x0, t0), a1 = __builtin_fmaf(s1, x1, t1);
+  a0 = a0 > 0.f ? a0 : 0.f;
+  a1 = a1 > 0.f ? a1 : 0.f;
+  hiw = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+  amax16 = pk_max_u16(amax16, hiw);
+  if (WITH_LO) {
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hiw), "v"(a0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hiw), "v"(a1));
+    low = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+  } else {
+    low = 0u;
+  }
+}
+
+// the two channel tiles of one k-step -> B fragment pair; S / T rows at channel 32 ks
+template <bool WITH_LO>
+__device__ __forceinline__ void act_kstep(const f32x4 &x0, const f32x4 &x1, const float *S, const float *T, int ch,
+                                          half8 &hi, half8 &lo, unsigned &amax16) {
+  const f32x4 s0 = *reinterpret_cast<const f32x4 *>(S + ch), t0 = *reinterpret_cast<const f32x4 *>(T + ch);
+  const f32x4 s1 = *reinterpret_cast<const f32x4 *>(S + ch + 16), t1 = *reinterpret_cast<const f32x4 *>(T + ch + 16);
+  unsigned hw[4], lw[4];
+  act2<WITH_LO>(x0[0], x0[1], s0[0], s0[1], t0[0], t0[1], hw[0], lw[0], amax16);
+  act2<WITH_LO>(x0[2], x0[3], s0[2], s0[3], t0[2], t0[3], hw[1], lw[1], amax16);
+  act2<WITH_LO>(x1[0], x1[1], s1[0], s1[1], t1[0], t1[1], hw[2], lw[2], amax16);
+  act2<WITH_LO>(x1[2], x1[3], s1[2], s1[3], t1[2], t1[3], hw[3], lw[3], amax16);
+  hi = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+  lo = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+}
+
+// wave w moves fragments 4w..4w+3 of a half
+__device__ __forceinline__ void dma_piece8(const half8 *__restrict__ packed, unsigned char *s_slots, int h, int j,
+                                           int wave, int lane) {
+  const int frag = wave * 4 + j;
+  const int hs = h >= N_HALVES ? h - N_HALVES : h;
+  __builtin_amdgcn_global_load_lds((gbl_void *)(packed + ((size_t)hs * HALF_FRAGS + frag) * 64 + lane),
+                                   (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, 0);
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(512) void occ_decode8_kernel(
+    int n_tiles, const float *__restrict__ pts, const int *__restrict__ tile_prop,
+    const int *__restrict__ tile_src, const half8 *__restrict__ packed, const float *__restrict__ fc_p_w,
+    const float *__restrict__ table, const float *__restrict__ fc_out_w, float fc_out_b,
+    float *__restrict__ logits, unsigned *status, int tiles_per_wg) {
+  constexpr bool X3 = TERMS == 3;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  float *s_tab = reinterpret_cast<float *>(smem);
+  float *s_wp = s_tab + ROWS * H;
+  float *s_wo = s_wp + H * 3;
+  unsigned char *s_slots = smem + SMEM_TAB_BYTES;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g4 = 4 * (lane >> 4), n = lane & 15;
+  unsigned amax16 = 0u;
+
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
+  int cur_prop = -1;
+  bool ring_primed = false;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int prop = tile_prop[tile];
+    if (prop < 0) continue;
+    const bool has_next = tile + 1 < t_end;
+    const size_t pidx = (size_t)tile * TILE + wave * 16 + n;
+    const size_t sidx = (size_t)(tile_src ? tile_src[tile] : tile) * TILE + wave * 16 + n;
+    const float px = pts[sidx * 3 + 0], py = pts[sidx * 3 + 1], pz = pts[sidx * 3 + 2];
+
+    if (!ring_primed) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) dma_piece8(packed, s_slots, j >> 2, j & 3, wave, lane);
+    }
+    if (prop != cur_prop) {
+      __syncthreads();
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(table + (size_t)prop * ROWS * H);
+      f32x4 *dst = reinterpret_cast<f32x4 *>(s_tab);
+      for (int i = t; i < ROWS * H / 4; i += 512) dst[i] = src[i];
+      if (!ring_primed) {
+        for (int i = t; i < H * 3; i += 512) s_wp[i] = fc_p_w[i];
+        if (t < H) s_wo[t] = fc_out_w[t];
+      }
+      cur_prop = prop;
+    }
+    ring_primed = true;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- fc_p (+ fc_z bias): H' = (Wp p + bp + zb) 2^KH
+    f32x4 Hs[16];
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * tt + g4 + r;
+        float v = s_tab[ch];
+        v = __builtin_fmaf(s_wp[ch * 3 + 0], px, v);
+        v = __builtin_fmaf(s_wp[ch * 3 + 1], py, v);
+        v = __builtin_fmaf(s_wp[ch * 3 + 2], pz, v);
+        Hs[tt][r] = v;
+      }
+
+    half8 ahi[8], alo[8];
+    for (int blk = 0; blk < NB; ++blk) {
+      const float *S0 = s_tab + (1 + 4 * blk) * H, *T0 = S0 + H, *S1 = T0 + H, *T1 = S1 + H;
+      // ---- block input a' = relu(S0' H' + T0'), fused with fc_0 of output block 0: k-step ks
+      // needs only channel tiles 2ks, 2ks+1, so k-step ks+1 is converted under its MFMAs
+      f32x4 acc_cur[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      {
+        const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * blk * 8) & 3) * HALF_BYTES) + lane;
+        act_kstep<X3>(Hs[0], Hs[1], S0, T0, g4, ahi[0], alo[0], amax16);
+        half8 n0h = w[0], n0l = w[64], n1h = w[128], n1l = w[192];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const half8 w0h = n0h, w0l = n0l, w1h = n1h, w1l = n1l;
+          if (ks < 7) {     // next k-step's fragments: LDS latency under this step's MFMAs
+            n0h = w[(4 * ks + 4) * 64];
+            n0l = w[(4 * ks + 5) * 64];
+            n1h = w[(4 * ks + 6) * 64];
+            n1l = w[(4 * ks + 7) * 64];
+            act_kstep<X3>(Hs[2 * ks + 2], Hs[2 * ks + 3], S0, T0, 32 * (ks + 1) + g4, ahi[ks + 1], alo[ks + 1], amax16);
+          }
+          acc_cur[0] = mfma16(w0h, ahi[ks], acc_cur[0]);
+          acc_cur[1] = mfma16(w1h, ahi[ks], acc_cur[1]);
+          if (X3) {
+            acc_cur[0] = mfma16(w0h, alo[ks], acc_cur[0]);
+            acc_cur[1] = mfma16(w1h, alo[ks], acc_cur[1]);
+            acc_cur[0] = mfma16(w0l, ahi[ks], acc_cur[0]);
+            acc_cur[1] = mfma16(w1l, ahi[ks], acc_cur[1]);
+          }
+        }
+      }
+      __syncthreads();
+
+      for (int mb = 0; mb < 8; ++mb) {
+        const int c = blk * 8 + mb;
+        // ---- epilogue of fc_0 block mb -> a2' (the B operand of fc_1's k-slab mb)
+        f32x4 acc_next[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        half8 bhi, blo;
+        act_kstep<X3>(acc_cur[0], acc_cur[1], S1, T1, 32 * mb + g4, bhi, blo, amax16);
+        // ---- phase A: fc_0 block mb+1 (two accumulator chains) with this iteration's LDS-DMA
+        // pieces in between
+        if (mb < 7) {
+          const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 2) & 3) * HALF_BYTES) + lane;
+          half8 n0h = w[0], n0l = w[64], n1h = w[128], n1l = w[192];
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const half8 w0h = n0h, w0l = n0l, w1h = n1h, w1l = n1l;
+            if (ks < 7) {
+              n0h = w[(4 * ks + 4) * 64];
+              n0l = w[(4 * ks + 5) * 64];
+              n1h = w[(4 * ks + 6) * 64];
+              n1l = w[(4 * ks + 7) * 64];
+            }
+            {
+              const int h = 2 * c + 3 + (ks >> 2);
+              if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, ks & 3, wave, lane);
+            }
+            acc_next[0] = mfma16(w0h, ahi[ks], acc_next[0]);
+            acc_next[1] = mfma16(w1h, ahi[ks], acc_next[1]);
+            if (X3) {
+              acc_next[0] = mfma16(w0h, alo[ks], acc_next[0]);
+              acc_next[1] = mfma16(w1h, alo[ks], acc_next[1]);
+              acc_next[0] = mfma16(w0l, ahi[ks], acc_next[0]);
+              acc_next[1] = mfma16(w1l, ahi[ks], acc_next[1]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int h = 2 * c + 3 + (j >> 2);
+            if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, j & 3, wave, lane);
+          }
+        }
+        // ---- phase B: H'[t] += fc_1[16t.., slab mb] a2', sixteen accumulators, two chains at a time
+        {
+          const half8 *w2 = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 1) & 3) * HALF_BYTES) + lane;
+          half8 n0h = w2[0], n0l = w2[64], n1h = w2[128], n1l = w2[192];
+#pragma unroll
+          for (int tp = 0; tp < 8; ++tp) {
+            const half8 c0h = n0h, c0l = n0l, c1h = n1h, c1l = n1l;
+            if (tp < 7) {
+              n0h = w2[(4 * tp + 4) * 64];
+              n0l = w2[(4 * tp + 5) * 64];
+              n1h = w2[(4 * tp + 6) * 64];
+              n1l = w2[(4 * tp + 7) * 64];
+            }
+            Hs[2 * tp] = mfma16(c0h, bhi, Hs[2 * tp]);
+            Hs[2 * tp + 1] = mfma16(c1h, bhi, Hs[2 * tp + 1]);
+            if (X3) {
+              Hs[2 * tp] = mfma16(c0h, blo, Hs[2 * tp]);
+              Hs[2 * tp + 1] = mfma16(c1h, blo, Hs[2 * tp + 1]);
+              Hs[2 * tp] = mfma16(c0l, bhi, Hs[2 * tp]);
+              Hs[2 * tp + 1] = mfma16(c1l, bhi, Hs[2 * tp + 1]);
+            }
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        acc_cur[0] = acc_next[0];
+        acc_cur[1] = acc_next[1];
+      }
+    }
+
+    // ---- out = fc_out(relu(CBN_f(h)))
+    const float *Sf = s_tab + 21 * H, *Tf = Sf + H;
+    float part = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+      const int ch0 = 16 * tt + g4;
+      const f32x4 s4 = *reinterpret_cast<const f32x4 *>(Sf + ch0);
+      const f32x4 t4 = *reinterpret_cast<const f32x4 *>(Tf + ch0);
+      const f32x4 w4 = *reinterpret_cast<const f32x4 *>(s_wo + ch0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = __builtin_fmaf(s4[e], Hs[tt][e], t4[e]);
+        a = a > 0.f ? a : 0.f;
+        part = __builtin_fmaf(w4[e], a, part);
+      }
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (lane < 16) logits[pidx] = part + fc_out_b;
+  }
+  if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(status, 2u);
+}
+
+}  // namespace
+
+RFD_API int rfd_occ_pack_weights_w8(const float *fc0_w, const float *fc1_w, const int *kw0, int kw1,
+                                    void *packed, void *stream) {
+  const int threads = 256;
+  const int blocks = (int)((PACKED_HALVES + threads - 1) / threads);
+  hipLaunchKernelGGL(pack8_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, fc0_w, fc1_w, kw0[0],
+                     kw0[1], kw0[2], kw0[3], kw0[4], kw1, (_Float16 *)packed);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API int rfd_occ_decode_w8(int n_tiles, const float *pts, const int *tile_prop, const int *tile_src,
+                              const void *packed, const float *fc_p_w, const float *table,
+                              const float *fc_out_w, float fc_out_b, float *logits, int mode, void *stream) {
+  if (n_tiles <= 0) return 0;
+  RfdWorkspace *ws;
+  int rc = rfd_get_workspace(&ws);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int ncu = ws->num_cu > 0 ? ws->num_cu : 256;
+  const int tiles_per_wg = ceil_div(n_tiles, ncu);
+  const int grid = ceil_div(n_tiles, tiles_per_wg);
+  if (mode == RFD_OCC_MODE_F16X3) {
+    hipLaunchKernelGGL(occ_decode8_kernel<3>, dim3(grid), dim3(512), 0, s, n_tiles, pts, tile_prop, tile_src,
+                       (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, ws->status, tiles_per_wg);
+  } else if (mode == RFD_OCC_MODE_F16X1) {
+    hipLaunchKernelGGL(occ_decode8_kernel<1>, dim3(grid), dim3(512), 0, s, n_tiles, pts, tile_prop, tile_src,
+                       (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, ws->status, tiles_per_wg);
+  } else {
+    rfd_set_error("rfd_occ_decode_w8: unknown mode", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  RFD_CHECK_LAUNCH();
+  return 0;
+}

@@ -10,6 +10,7 @@ num_batches_tracked}, blocks.{i}.{fc_0,fc_1}.{weight(256,256,1),bias}, bn.*,
 fc_out.{weight(1,256,1),bias}.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -82,6 +83,9 @@ class DecoderCBatchNorm(nn.Module):
         self.bn = CBatchNorm1d(c_dim, hidden_size)
         self.fc_out = nn.Conv1d(hidden_size, 1, 1)
         self.mode = MODE_F16X3
+        # which kernel: 'w4' = four 496-register waves per workgroup (csrc/occ_decoder.hip),
+        # 'w8' = eight waves, two per SIMD (csrc/occ_decoder8.hip); same results
+        self.kernel = os.environ.get("RFD_DECODER_KERNEL", "w8")
         self._packed = None
         self._packed_key = None
 
@@ -92,7 +96,7 @@ class DecoderCBatchNorm(nn.Module):
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
 
     def packed_weights(self):
-        key = self._weights_key()
+        key = self._weights_key() + (self.kernel,)
         if self._packed is None or key != self._packed_key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             fc0, fc1 = occ_fold.stacked_fc_weights(sd)
@@ -104,8 +108,8 @@ class DecoderCBatchNorm(nn.Module):
                                  device=fc0.device)
             arr = (C.c_int * 5)(*kw0)
             with torch.cuda.device(fc0.device):
-                rc = _lib.lib().rfd_occ_pack_weights(fc0.data_ptr(), fc1.data_ptr(), arr, kw1,
-                                                     packed.data_ptr(), _lib.current_stream())
+                pack = _lib.lib().rfd_occ_pack_weights_w8 if self.kernel == "w8" else _lib.lib().rfd_occ_pack_weights
+                rc = pack(fc0.data_ptr(), fc1.data_ptr(), arr, kw1, packed.data_ptr(), _lib.current_stream())
             _lib.check(rc, "rfd_occ_pack_weights")
             self._packed = (packed, kw0, kw1)
             self._packed_key = key
@@ -147,12 +151,12 @@ class DecoderCBatchNorm(nn.Module):
         wo = self.fc_out.weight.detach().reshape(-1).contiguous()
         bo = self._fc_out_bias()
         with torch.cuda.device(pts.device):
-            rc = _lib.lib().rfd_occ_decode(n_tiles, pts.data_ptr(), tile_prop.data_ptr(),
-                                           tile_src.data_ptr() if tile_src is not None else None,
-                                           packed.data_ptr(), fc_p_w.data_ptr(), table.data_ptr(),
-                                           wo.data_ptr(), bo, logits.data_ptr(),
-                                           self.mode if mode is None else mode,
-                                           _lib.current_stream())
+            decode = _lib.lib().rfd_occ_decode_w8 if self.kernel == "w8" else _lib.lib().rfd_occ_decode
+            rc = decode(n_tiles, pts.data_ptr(), tile_prop.data_ptr(),
+                        tile_src.data_ptr() if tile_src is not None else None,
+                        packed.data_ptr(), fc_p_w.data_ptr(), table.data_ptr(),
+                        wo.data_ptr(), bo, logits.data_ptr(),
+                        self.mode if mode is None else mode, _lib.current_stream())
         _lib.check(rc, "rfd_occ_decode")
         return logits
 
