@@ -3,7 +3,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rfdnet_amd import synthetic, _lib
-if os.environ.get("RFD_LIB"): _lib.LIB_PATH = os.environ["RFD_LIB"]
+
 from rfdnet_amd.iscnet.occ_decoder import DecoderCBatchNorm
 K, T = 256, 32768
 dec = DecoderCBatchNorm(dim=3, z_dim=32, c_dim=512, hidden_size=256)
