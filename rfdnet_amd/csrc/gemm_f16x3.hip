@@ -258,6 +258,67 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Epilogue of the row-owner kernels: each wave transposes its 32 x 256 block through 16 KiB
+// of (now idle) LDS, 128 columns at a time, and writes 512 contiguous bytes per row
+// (row-scattered 16-byte stores from the accumulator layout run at ~8 B/clk/CU); lane l of a
+// row handles columns 4l..4l+3, so bias + group bias (never null here: the host passes a zero
+// vector for an absent one) are loaded once per pass.  16-byte chunks are XOR-swizzled by the
+// row (conflict-free on both sides, no padding).  Optional fused max-pool over the group.
+template <bool HAS_RES>
+__device__ __forceinline__ void rows_epilogue(const Args &g, unsigned char *smem, const f32x16 (&acc)[8], int wave,
+                                              int lane, int m0, int n0) {
+  const int half = lane >> 5, n = lane & 31;
+  {
+    float *tr = reinterpret_cast<float *>(smem + wave * 16384);
+    const int l = lane & 31, rsel = lane >> 5;
+    const float *grow = g.gbias + (size_t)(m0 / g.rows_per_group) * g.gbias_stride + n0 + 4 * l;
+    const float *brow = g.bias + n0 + 4 * l;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f32x4 cb = *reinterpret_cast<const f32x4 *>(brow + 128 * p) +
+                       *reinterpret_cast<const f32x4 *>(grow + 128 * p);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int chunk = 8 * bb + 2 * q + half;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[4 * p + bb][4 * q + e];
+          *reinterpret_cast<f32x4 *>(tr + n * 128 + ((chunk ^ n) * 4)) = v;
+        }
+      f32x4 pmax = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int j = 0; j < 16; ++j) {
+        const int row = 2 * j + rsel;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(tr + row * 128 + ((l ^ row) * 4));
+        const size_t m = (size_t)(m0 + row);
+        f32x4 add = cb;
+        if (HAS_RES) add += *reinterpret_cast<const f32x4 *>(g.R + m * g.ldr + n0 + 128 * p + 4 * l);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = __builtin_fmaf(a[e], g.out_scale, add[e]);
+          if (g.relu_out) o[e] = o[e] > 0.f ? o[e] : 0.f;
+          pmax[e] = o[e] > pmax[e] ? o[e] : pmax[e];
+        }
+        if (g.C) *reinterpret_cast<f32x4 *>(g.C + m * g.ldc + n0 + 128 * p + 4 * l) = o;   // C may be omitted when only the pool is wanted
+      }
+      if (g.pool) {
+        // fused max-pool over the group's rows (every consumer rectifies the pooled vector, so
+        // max(0, .) is what is needed): non-negative floats order like their bit patterns
+        int *pp = reinterpret_cast<int *>(g.pool + (size_t)(m0 / g.rows_per_group) * g.N + n0 + 128 * p + 4 * l);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float other = __shfl_xor(pmax[e], 32);
+          const float v = other > pmax[e] ? other : pmax[e];
+          if (rsel == 0 && v > 0.f) atomicMax(pp + e, __float_as_int(v));
+        }
+      }
+    }
+  }
+}
+
 // 8 waves per workgroup: a wave owns 32 rows x 256 columns (8 accumulator blocks, <= 256
 // registers), so TWO waves share each SIMD: while one is stuck issuing a vector-memory
 // instruction, parked at a wait or in its epilogue, the other keeps the matrix pipe busy
@@ -406,56 +467,8 @@ __global__ __launch_bounds__(512) void gemm_rows8_kernel(Args g) {
     }
   }
   wait_vm<0>();
-  __builtin_amdgcn_s_barrier();
-  {
-    float *tr = reinterpret_cast<float *>(smem + wave * 16384);
-    const int l = lane & 31, rsel = lane >> 5;
-    const float *grow = g.gbias + (size_t)(m0 / g.rows_per_group) * g.gbias_stride + n0 + 4 * l;
-    const float *brow = g.bias + n0 + 4 * l;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const f32x4 cb = *reinterpret_cast<const f32x4 *>(brow + 128 * p) +
-                       *reinterpret_cast<const f32x4 *>(grow + 128 * p);
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int chunk = 8 * bb + 2 * q + half;
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[4 * p + bb][4 * q + e];
-          *reinterpret_cast<f32x4 *>(tr + n * 128 + ((chunk ^ n) * 4)) = v;
-        }
-      f32x4 pmax = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-      for (int j = 0; j < 16; ++j) {
-        const int row = 2 * j + rsel;
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(tr + row * 128 + ((l ^ row) * 4));
-        const size_t m = (size_t)(m0 + row);
-        f32x4 add = cb;
-        if (HAS_RES) add += *reinterpret_cast<const f32x4 *>(g.R + m * g.ldr + n0 + 128 * p + 4 * l);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = __builtin_fmaf(a[e], g.out_scale, add[e]);
-          if (g.relu_out) o[e] = o[e] > 0.f ? o[e] : 0.f;
-          pmax[e] = o[e] > pmax[e] ? o[e] : pmax[e];
-        }
-        if (g.C) *reinterpret_cast<f32x4 *>(g.C + m * g.ldc + n0 + 128 * p + 4 * l) = o;   // C may be omitted when only the pool is wanted
-      }
-      if (g.pool) {
-        // fused max-pool over the group's rows (every consumer rectifies the pooled vector, so
-        // max(0, .) is what is needed): non-negative floats order like their bit patterns
-        int *pp = reinterpret_cast<int *>(g.pool + (size_t)(m0 / g.rows_per_group) * g.N + n0 + 128 * p + 4 * l);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float other = __shfl_xor(pmax[e], 32);
-          const float v = other > pmax[e] ? other : pmax[e];
-          if (rsel == 0 && v > 0.f) atomicMax(pp + e, __float_as_int(v));
-        }
-      }
-    }
-  }
+  __builtin_amdgcn_s_barrier();    // every wave's W transfers have landed: the ring is free
+  rows_epilogue<HAS_RES>(g, smem, acc, wave, lane, m0, n0);
 }
 
 }  // namespace

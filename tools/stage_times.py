@@ -6,9 +6,10 @@ from rfdnet_amd import synthetic
 from rfdnet_amd.iscnet.config import Config
 from rfdnet_amd.iscnet.network import ISCNet
 
-cfg = Config({'generation': {'resolution_0': 32, 'upsampling_steps': 1}})
+import os
+cfg = Config({'data': {'num_point': int(os.environ.get('ST_POINTS', 80000))}, 'generation': {'resolution_0': 32, 'upsampling_steps': int(os.environ.get('ST_STEPS', 1))}})
 net = ISCNet(cfg); synthetic.load_seeded(net, 10); net = net.cuda().eval()
-pc = torch.from_numpy(synthetic.synthetic_scene(seed=10, n_points=80000)[None]).cuda()
+pc = torch.from_numpy(synthetic.synthetic_scene(seed=10, n_points=int(os.environ.get('ST_POINTS', 80000)))[None]).cuda()
 
 
 class T:
