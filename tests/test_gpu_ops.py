@@ -197,11 +197,14 @@ def test_grad_ops_match_oracle(ext, oracle):
                                oracle.three_interpolate_grad(go2, i3, w, n), rtol=1e-5, atol=1e-5)
 
 
-def test_group_concat_equals_reference_composition(ext, oracle):
+@pytest.mark.parametrize("b,c,n,m,ns", [(2, 6, 3000, 200, 16),        # gather from L2 (table too large for LDS)
+                                        (2, 128, 2048, 1024, 32),     # SA2: gather from LDS
+                                        (3, 13, 512, 130, 6)])        # LDS, ragged channel chunk and slab
+def test_group_concat_equals_reference_composition(ext, oracle, b, c, n, m, ns):
     """fused QueryAndGroup epilogue == group(xyz^T) - centre, / radius, cat features
     (pointnet2_utils.py:333-344), bit for bit"""
     rng = np.random.default_rng(12)
-    b, c, n, m, ns, r = 2, 6, 3000, 200, 16, 0.37
+    r = 0.37
     xyz = np.stack([scene(rng, n) for _ in range(b)])
     feats = rng.normal(size=(b, c, n)).astype(np.float32)
     new = xyz[:, :m].copy()

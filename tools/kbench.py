@@ -46,7 +46,9 @@ def main():
     c2 = new[:, :1024].contiguous()
     idx2 = _ext.ball_query(c2, x2, 0.4, 32)
     res["group_sa2_131x1024x32_ms"] = timeit(lambda: _ext.group_concat(x2, c2, feats, idx2, 0.4, True, True, True))
-    nbytes = 131 * 1024 * 32 * 4 * 2 + 1024 * 32 * 4
+    # HBM-side algorithmic bytes: output written once, indices + (C,N) table + xyz read once
+    # (the gathered element reads are served on chip: LDS for N <= 2048, L2 otherwise)
+    nbytes = 131 * 1024 * 32 * 4 + 1024 * 32 * 4 + 128 * 2048 * 4 + 2048 * 12 + 1024 * 12
     res["group_sa2_GBps"] = nbytes / res["group_sa2_131x1024x32_ms"] / 1e6
     # batched grouping (B=32) to show the bandwidth regime
     fb = torch.randn(32, 128, 2048, device="cuda")
