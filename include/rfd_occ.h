@@ -134,19 +134,23 @@ int rfd_mise_to_dense(int K, int res0, int depth, float *values,
 /* ---- batched marching cubes (generator.py:157-161; PyMCubes 0.1.2 is not
  * vendored: published algorithm restated, ordering is ours) ----------------------
  * grids [K][n][n][n] f32; the -1e6 padding shell of generator.py:158-159 is
- * virtual: D = n + 2 lattice points per axis.  classify fills ebits[K][D^3]
- * (crossed +x/+y/+z edges of each lattice point), vcount / tcount [K][D^3]
- * (vertices owned by the point / triangles of the cell).  The caller takes
- * EXCLUSIVE prefix sums vbase / tbase of the flattened count arrays, sizes the
- * outputs, then emit writes verts [NV][3] f64 in padded-grid index coordinates
- * (original grid point i sits at i + 1) and tris [NT][3] i32 with vertex
- * indices local to each proposal.  Corner c is "outside" when value < iso;
+ * virtual: D = n + 2 lattice points per axis.  Workgroups own rfd_mc_blocks(n)
+ * runs of consecutive lattice points per proposal.  classify fills code[K][D^3]
+ * (the 8-bit cube index of the cell whose origin is the lattice point; the crossed
+ * +x/+y/+z edges = vertices the point owns, and the triangle count, follow from
+ * it) and the per-workgroup totals vsum / tsum
+ * [K][rfd_mc_blocks(n)].  The caller takes EXCLUSIVE prefix sums vblock / tblock of
+ * the flattened totals, sizes the outputs, then emit writes verts [NV][3] f64 in
+ * padded-grid index coordinates (original grid point i sits at i + 1) and tris
+ * [NT][3] i32 with vertex indices local to each proposal; vbase [K][D^3] i32 is
+ * scratch (no initialisation needed).  Corner c is "outside" when value < iso;
  * triangle normals point outside. */
+int rfd_mc_blocks(int n);
 int rfd_mc_classify(int K, int n, float pad_value, double iso, const float *grids,
-                    unsigned char *ebits, int *vcount, int *tcount, void *stream);
+                    unsigned char *code, int *vsum, int *tsum, void *stream);
 int rfd_mc_emit(int K, int n, float pad_value, double iso, const float *grids,
-                const unsigned char *ebits, const int *vbase, const int *tcount,
-                const int *tbase, double *verts, int *tris, void *stream);
+                const unsigned char *code, const int *vblock, const int *tblock,
+                int *vbase, double *verts, int *tris, void *stream);
 
 /* ---- proposal post-processing (net_utils/ap_helper.py:131-264 parse_predictions,
  * net_utils/nms.py:79-118, net_utils/libs.py:128-137: CPU numpy + scipy Delaunay

@@ -50,6 +50,7 @@ SIGNATURES = {
     "rfd_resblock_f16x3": [_i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _f],
     "rfd_mc_classify": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f],
     "rfd_mc_emit": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f, _f, _f, _f],
+    "rfd_mc_blocks": [_i],
 }
 _RESTYPES = {
     "rfd_last_error_string": C.c_char_p,

@@ -11,12 +11,17 @@
 //
 // All K proposals are processed by the same launches; the -1e6 padding shell is
 // virtual (never materialised).  Three passes over K*D^3 lattice points
-// (D = n + 2), all HBM-bound and coalesced along z:
-//   classify : per point  -> crossed +x/+y/+z edge bits, #vertices it owns,
-//              per cell   -> #triangles
-//   (exclusive scans of the two count arrays are done by the caller)
-//   vertices : one vertex per crossed edge, index = scan[point] + rank of axis
-//   triangles: table lookup, vertex index via the owner point's scan value
+// (D = n + 2), workgroup = a run of MC_RUN consecutive points of one proposal.
+// The only per-point state kept in HBM is ONE byte (the cube index of the point's cell)
+// plus a sparse int32 vertex base for points that own a vertex; prefix sums are two-level
+// (per-workgroup sums -> tiny scan by the caller -> in-workgroup scan recomputed where
+// needed), so no dense int32 count / scan arrays are written or read:
+//   classify : point -> code byte; workgroup -> (#vertices, #triangles)
+//   vertices : one vertex per crossed edge, index = workgroup base + in-workgroup scan;
+//              leaves that index in vbase[point] for the triangle pass
+//   triangles: table lookup, vertex index via the owner point's vbase
+// HBM traffic per point: 4 B of grid + 1 B written (classify), 1 B read twice (emit),
+// vs 4 + 9 written, 2 x 16 for scans / differences and 13 read in the dense-array version.
 // Vertex coordinates are in padded-grid index space (grid point i of the
 // original grid sits at i + 1), double precision like the reference's float64
 // grid.
@@ -30,122 +35,225 @@ __constant__ signed char c_tri[256][3 * MC_MAX_TRIS];
 __constant__ signed char c_owner[12][4];
 bool g_tables_uploaded[64] = {false};
 
+constexpr int MC_BLOCK = 256;
+constexpr int MC_PTS = 4;                    // consecutive lattice points per thread
+constexpr int MC_RUN = MC_BLOCK * MC_PTS;     // points per workgroup = unit of the two-level scan
+
+// Smallest float >= iso: for a float v, ((double)v < iso) == (v < float_ceil(iso)).
+__device__ __forceinline__ float float_ceil(double iso) {
+  float t = (float)iso;
+  if ((double)t < iso) t = __uint_as_float(__float_as_uint(t) + (t >= 0.f ? 1 : -1));
+  return t;
+}
+
 struct GridView {
   const float *g;  // [n][n][n] of this proposal
   int n, D;
   float pad;
+  // branch-free: clamp the address, select the padding value afterwards (lets the compiler
+  // issue all corner loads of a thread back to back)
   __device__ __forceinline__ float at(int i, int j, int k) const {
-    if (i <= 0 || j <= 0 || k <= 0 || i >= D - 1 || j >= D - 1 || k >= D - 1) return pad;
-    return g[((size_t)(i - 1) * n + (j - 1)) * n + (k - 1)];
+    const bool in = i > 0 && j > 0 && k > 0 && i < D - 1 && j < D - 1 && k < D - 1;
+    const int ci = min(max(i - 1, 0), n - 1), cj = min(max(j - 1, 0), n - 1),
+              ck = min(max(k - 1, 0), n - 1);
+    float v = g[(unsigned)((ci * n + cj) * n + ck)];
+    asm("" : "+v"(v));  // keep the load unconditional (else it is sunk under a branch on `in`)
+    return in ? v : pad;
   }
 };
 
-__global__ __launch_bounds__(256) void mc_classify_kernel(
-    int n, float pad, double iso, const float *__restrict__ grids,
-    unsigned char *__restrict__ ebits, int *__restrict__ vcount, int *__restrict__ tcount) {
-  const int D = n + 2;
-  const size_t per = (size_t)D * D * D;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per) return;
-  const int kp = blockIdx.y;
-  const int k = (int)(e % D), j = (int)((e / D) % D), i = (int)(e / ((size_t)D * D));
-  GridView G{grids + (size_t)kp * n * n * n, n, D, pad};
-  // corner values of the cell whose origin is this point (Bourke numbering)
-  const bool hasx = i + 1 < D, hasy = j + 1 < D, hasz = k + 1 < D;
-  const float v0 = G.at(i, j, k);
-  const float v1 = hasx ? G.at(i + 1, j, k) : pad;
-  const float v3 = hasy ? G.at(i, j + 1, k) : pad;
-  const float v4 = hasz ? G.at(i, j, k + 1) : pad;
-  const bool b0 = (double)v0 < iso;
-  unsigned bits = 0;
-  if (hasx && (((double)v1 < iso) != b0)) bits |= 1u;
-  if (hasy && (((double)v3 < iso) != b0)) bits |= 2u;
-  if (hasz && (((double)v4 < iso) != b0)) bits |= 4u;
-  int nt = 0;
-  if (hasx && hasy && hasz) {
-    const float v2 = G.at(i + 1, j + 1, k), v5 = G.at(i + 1, j, k + 1);
-    const float v6 = G.at(i + 1, j + 1, k + 1), v7 = G.at(i, j + 1, k + 1);
-    unsigned ci = (b0 ? 1u : 0u) | (((double)v1 < iso) ? 2u : 0u) | (((double)v2 < iso) ? 4u : 0u) |
-                  (((double)v3 < iso) ? 8u : 0u) | (((double)v4 < iso) ? 16u : 0u) |
-                  (((double)v5 < iso) ? 32u : 0u) | (((double)v6 < iso) ? 64u : 0u) |
-                  (((double)v7 < iso) ? 128u : 0u);
-    nt = c_ntri[ci];
+struct Point {
+  int i, j, k;
+  __device__ __forceinline__ Point(unsigned e, unsigned D) {
+    const unsigned r = e / D;
+    k = (int)(e - r * D);
+    i = (int)(r / D);
+    j = (int)(r - (unsigned)i * D);
   }
-  const size_t o = (size_t)kp * per + e;
-  ebits[o] = (unsigned char)bits;
-  vcount[o] = __popc(bits);
-  tcount[o] = nt;
-}
+};
 
-__global__ __launch_bounds__(256) void mc_vertices_kernel(
-    int n, float pad, double iso, const float *__restrict__ grids,
-    const unsigned char *__restrict__ ebits, const int *__restrict__ vbase,
-    double *__restrict__ verts) {
-  const int D = n + 2;
-  const size_t per = (size_t)D * D * D;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per) return;
-  const int kp = blockIdx.y;
-  const size_t o = (size_t)kp * per + e;
-  const unsigned bits = ebits[o];
-  if (!bits) return;
-  const int k = (int)(e % D), j = (int)((e / D) % D), i = (int)(e / ((size_t)D * D));
-  GridView G{grids + (size_t)kp * n * n * n, n, D, pad};
-  const double f1 = (double)G.at(i, j, k);
-  int vi = vbase[o];
+// Exclusive scan of x over the workgroup (MC_BLOCK threads); *total = sum over the workgroup.
+__device__ __forceinline__ int block_scan(int x, int *total) {
+  __shared__ int wsum[MC_BLOCK / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = x;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    if (!(bits & (1u << a))) continue;
-    const double f2 = (double)G.at(i + (a == 0), j + (a == 1), k + (a == 2));
-    // linear interpolation along the edge (x2 - x1 = 1)
-    const double mu = (f2 == f1) ? 0.5 : (iso - f1) / (f2 - f1);
-    double p[3] = {(double)i, (double)j, (double)k};
-    p[a] += mu;
-    verts[(size_t)vi * 3 + 0] = p[0];
-    verts[(size_t)vi * 3 + 1] = p[1];
-    verts[(size_t)vi * 3 + 2] = p[2];
-    ++vi;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(inc, d);
+    if (lane >= d) inc += y;
   }
+  __syncthreads();  // wsum may still be read by a previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int q = 0; q < MC_BLOCK / 64; ++q) {
+    if (q < w) off += wsum[q];
+    tot += wsum[q];
+  }
+  *total = tot;
+  return off + inc - x;
 }
 
-__global__ __launch_bounds__(256) void mc_triangles_kernel(
+// crossed +x / +y / +z edges of the cell origin, from the cube index (corner 0 vs 1, 3, 4)
+__device__ __forceinline__ unsigned edge_bits(unsigned ci) {
+  return (((ci >> 1) ^ ci) & 1u) | ((((ci >> 3) ^ ci) & 1u) << 1) | ((((ci >> 4) ^ ci) & 1u) << 2);
+}
+
+// code[point] = cube index of the cell whose origin is the point, over the padded lattice
+// extended by one more virtual padding layer (cells on the far faces see only padding:
+// index 255, no triangles, no edges -- the same result as "no such cell").
+// A workgroup owns a run of MC_RUN consecutive points, four per thread: the 32 corner loads
+// of a thread are independent and the per-run scan covers 4x the points (these passes were
+// bound by workgroup latency x rounds, not by bandwidth).  In the emit kernels thread t owns
+// the points 4t .. 4t+3 so that the scan order is the point order.
+__global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(
     int n, float pad, double iso, const float *__restrict__ grids,
-    const unsigned char *__restrict__ ebits, const int *__restrict__ vbase,
-    const int *__restrict__ tcount, const int *__restrict__ tbase, int *__restrict__ tris) {
+    unsigned char *__restrict__ code, int *__restrict__ vsum, int *__restrict__ tsum) {
   const int D = n + 2;
-  const size_t per = (size_t)D * D * D;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per) return;
+  const unsigned per = (unsigned)D * D * D;
   const int kp = blockIdx.y;
-  const size_t o = (size_t)kp * per + e;
-  const int nt = tcount[o];
-  if (!nt) return;
-  const int k = (int)(e % D), j = (int)((e / D) % D), i = (int)(e / ((size_t)D * D));
+  const float thr = float_ceil(iso);
+  // only the run TOTALS are needed here, so lanes take consecutive points (coalesced loads)
+  const unsigned e = blockIdx.x * MC_RUN + threadIdx.x;
   GridView G{grids + (size_t)kp * n * n * n, n, D, pad};
-  unsigned ci = 0;
+  // Bourke corner numbering
   const int cx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, cy[8] = {0, 0, 1, 1, 0, 0, 1, 1},
             cz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  int cnt = 0;
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
-    if ((double)G.at(i + cx[c], j + cy[c], k + cz[c]) < iso) ci |= 1u << c;
-  const int v0 = vbase[(size_t)kp * per];  // first vertex of this proposal
-  int t = tbase[o];
-  for (int q = 0; q < nt; ++q) {
+  for (int p = 0; p < MC_PTS; ++p) {
+    const unsigned ep = e + p * MC_BLOCK;
+    if (ep < per) {
+      const Point P(ep, D);
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = G.at(P.i + cx[c], P.j + cy[c], P.k + cz[c]);
+      unsigned ci = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ci |= (v[c] < thr ? 1u : 0u) << c;
+      code[(size_t)kp * per + ep] = (unsigned char)ci;
+      cnt += __popc(edge_bits(ci)) | ((int)c_ntri[ci] << 16);
+    }
+  }
+  // per-run totals: vertices in the low half, triangles in the high half (<= 3072 / 5120)
+  int total;
+  block_scan(cnt, &total);
+  if (threadIdx.x == 0) {
+    vsum[(size_t)kp * gridDim.x + blockIdx.x] = total & 0xffff;
+    tsum[(size_t)kp * gridDim.x + blockIdx.x] = total >> 16;
+  }
+}
+
+// Phase 1 (thread per 4 points): scan the vertex counts, leave each owner's first vertex index
+// in vbase and list the owners in LDS.  Phase 2 (thread per VERTEX): interpolate and store --
+// the surface touches ~5 % of the points, so a thread-per-point emit leaves most lanes idle.
+__global__ __launch_bounds__(MC_BLOCK) void mc_vertices_kernel(
+    int n, float pad, double iso, const float *__restrict__ grids,
+    const unsigned char *__restrict__ code, const int *__restrict__ vblock,
+    int *__restrict__ vbase, double *__restrict__ verts) {
+  __shared__ unsigned short owner[MC_RUN * 3];
+  __shared__ unsigned short first[MC_RUN];
+  __shared__ unsigned char sbits[MC_RUN];
+  const int D = n + 2;
+  const unsigned per = (unsigned)D * D * D;
+  const int kp = blockIdx.y;
+  const unsigned e0 = blockIdx.x * MC_RUN, e = e0 + threadIdx.x * MC_PTS;
+  unsigned bits[MC_PTS];
+  int mine = 0;
+#pragma unroll
+  for (int p = 0; p < MC_PTS; ++p) {
+    bits[p] = e + p < per ? edge_bits(code[(size_t)kp * per + e + p]) : 0u;
+    mine += __popc(bits[p]);
+  }
+  int total;
+  int off = block_scan(mine, &total);
+  if (total == 0) return;
+  const int base = vblock[(size_t)kp * gridDim.x + blockIdx.x];
+#pragma unroll
+  for (int p = 0; p < MC_PTS; ++p) {
+    const int c = threadIdx.x * MC_PTS + p;
+    first[c] = (unsigned short)off;
+    sbits[c] = (unsigned char)bits[p];
+    if (bits[p]) {
+      vbase[(size_t)kp * per + e + p] = base + off;
+      for (int q = 0; q < __popc(bits[p]); ++q) owner[off + q] = (unsigned short)c;
+      off += __popc(bits[p]);
+    }
+  }
+  __syncthreads();
+  GridView G{grids + (size_t)kp * n * n * n, n, D, pad};
+  for (int t = threadIdx.x; t < total; t += MC_BLOCK) {
+    const int c = owner[t];
+    int q = t - first[c];
+    unsigned b = sbits[c];
+    while (q--) b &= b - 1;          // drop the q lowest crossed edges
+    const int a = __ffs(b) - 1;      // axis of this vertex
+    const Point P(e0 + c, D);
+    const double f1 = (double)G.at(P.i, P.j, P.k);
+    const double f2 = (double)G.at(P.i + (a == 0), P.j + (a == 1), P.k + (a == 2));
+    // linear interpolation along the edge (x2 - x1 = 1)
+    const double mu = (f2 == f1) ? 0.5 : (iso - f1) / (f2 - f1);
+    double *o = verts + (size_t)(base + t) * 3;
+    o[0] = (double)P.i + (a == 0 ? mu : 0.0);
+    o[1] = (double)P.j + (a == 1 ? mu : 0.0);
+    o[2] = (double)P.k + (a == 2 ? mu : 0.0);
+  }
+}
+
+// Same two phases for the triangles (thread per TRIANGLE in phase 2).
+__global__ __launch_bounds__(MC_BLOCK) void mc_triangles_kernel(
+    int n, const unsigned char *__restrict__ code, const int *__restrict__ vblock,
+    const int *__restrict__ tblock, const int *__restrict__ vbase, int *__restrict__ tris) {
+  __shared__ unsigned short owner[MC_RUN * MC_MAX_TRIS];
+  __shared__ unsigned short first[MC_RUN];
+  __shared__ unsigned char sci[MC_RUN];
+  const int D = n + 2;
+  const unsigned per = (unsigned)D * D * D;
+  const int kp = blockIdx.y;
+  const unsigned char *pc = code + (size_t)kp * per;
+  const unsigned e0 = blockIdx.x * MC_RUN, e = e0 + threadIdx.x * MC_PTS;
+  unsigned ci[MC_PTS];
+  int mine = 0;
+#pragma unroll
+  for (int p = 0; p < MC_PTS; ++p) {
+    ci[p] = e + p < per ? pc[e + p] : 255u;
+    mine += c_ntri[ci[p]];
+  }
+  int total;
+  int off = block_scan(mine, &total);
+  if (total == 0) return;
+#pragma unroll
+  for (int p = 0; p < MC_PTS; ++p) {
+    const int c = threadIdx.x * MC_PTS + p;
+    const int nt = c_ntri[ci[p]];
+    first[c] = (unsigned short)off;
+    sci[c] = (unsigned char)ci[p];
+    for (int q = 0; q < nt; ++q) owner[off + q] = (unsigned short)c;
+    off += nt;
+  }
+  __syncthreads();
+  const int base = tblock[(size_t)kp * gridDim.x + blockIdx.x];
+  const int v0 = vblock[(size_t)kp * gridDim.x];  // first vertex of this proposal
+  const int *pv = vbase + (size_t)kp * per;
+  for (int t = threadIdx.x; t < total; t += MC_BLOCK) {
+    const int c = owner[t];
+    const int q = t - first[c];
+    const unsigned cc = sci[c];
+    const unsigned ec = e0 + c;
     int idx[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const int ed = c_tri[ci][3 * q + r];
-      const size_t op = (size_t)kp * per +
-                        ((size_t)(i + c_owner[ed][0]) * D + (j + c_owner[ed][1])) * D +
-                        (k + c_owner[ed][2]);
-      const unsigned ob = ebits[op];
+      const int ed = c_tri[cc][3 * q + r];
+      const unsigned op = ec + (unsigned)((c_owner[ed][0] * D + c_owner[ed][1]) * D + c_owner[ed][2]);
+      const unsigned ob = edge_bits(pc[op]);
       const int axis = c_owner[ed][3];
-      idx[r] = vbase[op] + __popc(ob & ((1u << axis) - 1u)) - v0;
+      idx[r] = pv[op] + __popc(ob & ((1u << axis) - 1u)) - v0;
     }
-    tris[(size_t)t * 3 + 0] = idx[0];
-    tris[(size_t)t * 3 + 1] = idx[1];
-    tris[(size_t)t * 3 + 2] = idx[2];
-    ++t;
+    int *o = tris + (size_t)(base + t) * 3;
+    o[0] = idx[0];
+    o[1] = idx[1];
+    o[2] = idx[2];
   }
 }
 
@@ -162,35 +270,39 @@ int upload_tables() {
 
 }  // namespace
 
-// grids [K][n][n][n] f32; ebits [K][D^3] u8, vcount/tcount [K][D^3] i32 (D = n+2)
+RFD_API int rfd_mc_blocks(int n) {
+  const size_t per = (size_t)(n + 2) * (n + 2) * (n + 2);
+  return (int)((per + MC_RUN - 1) / MC_RUN);
+}
+
+// grids [K][n][n][n] f32; code [K][D^3] u8 (D = n+2); vsum / tsum [K][rfd_mc_blocks(n)] i32
 RFD_API int rfd_mc_classify(int K, int n, float pad_value, double iso, const float *grids,
-                            unsigned char *ebits, int *vcount, int *tcount, void *stream) {
+                            unsigned char *code, int *vsum, int *tsum, void *stream) {
   if (K <= 0 || n <= 0) return 0;
   int rc = upload_tables();
   if (rc) return rc;
-  const size_t per = (size_t)(n + 2) * (n + 2) * (n + 2);
-  hipLaunchKernelGGL(mc_classify_kernel, dim3((unsigned)((per + 255) / 256), K), dim3(256), 0,
-                     (hipStream_t)stream, n, pad_value, iso, grids, ebits, vcount, tcount);
+  hipLaunchKernelGGL(mc_classify_kernel, dim3((unsigned)rfd_mc_blocks(n), K), dim3(MC_BLOCK), 0,
+                     (hipStream_t)stream, n, pad_value, iso, grids, code, vsum, tsum);
   RFD_CHECK_LAUNCH();
   return 0;
 }
 
-// vbase/tbase: EXCLUSIVE prefix sums of vcount/tcount over the flattened
-// [K][D^3] arrays.  verts [NV][3] f64 (padded-grid index coordinates),
-// tris [NT][3] i32 with vertex indices LOCAL to each proposal.
+// vblock / tblock: EXCLUSIVE prefix sums of vsum / tsum over the flattened [K][blocks]
+// arrays.  vbase [K][D^3] i32 scratch (written where a point owns a vertex).  verts [NV][3]
+// f64 (padded-grid index coordinates), tris [NT][3] i32 with vertex indices LOCAL to each
+// proposal.
 RFD_API int rfd_mc_emit(int K, int n, float pad_value, double iso, const float *grids,
-                        const unsigned char *ebits, const int *vbase, const int *tcount,
-                        const int *tbase, double *verts, int *tris, void *stream) {
+                        const unsigned char *code, const int *vblock, const int *tblock,
+                        int *vbase, double *verts, int *tris, void *stream) {
   if (K <= 0 || n <= 0) return 0;
   int rc = upload_tables();
   if (rc) return rc;
-  const size_t per = (size_t)(n + 2) * (n + 2) * (n + 2);
-  const dim3 grid((unsigned)((per + 255) / 256), K);
-  hipLaunchKernelGGL(mc_vertices_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, pad_value,
-                     iso, grids, ebits, vbase, verts);
+  const dim3 grid((unsigned)rfd_mc_blocks(n), K);
+  hipLaunchKernelGGL(mc_vertices_kernel, grid, dim3(MC_BLOCK), 0, (hipStream_t)stream, n,
+                     pad_value, iso, grids, code, vblock, vbase, verts);
   RFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(mc_triangles_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, pad_value,
-                     iso, grids, ebits, vbase, tcount, tbase, tris);
+  hipLaunchKernelGGL(mc_triangles_kernel, grid, dim3(MC_BLOCK), 0, (hipStream_t)stream, n, code,
+                     vblock, tblock, vbase, tris);
   RFD_CHECK_LAUNCH();
   return 0;
 }

@@ -263,6 +263,72 @@ __global__ void mise_subdivide_kernel(int R1, int res0, int depth, int l, double
       }
 }
 
+// The same level for s = 2^(depth-l) <= 4, staged through LDS.  A workgroup owns a slab of
+// 1 x SUB_TJ x SUB_TK voxels; the (s+1) x (SUB_TJ*s+1) x (SUB_TK*s+1) grid points it touches
+// are read once, coalesced along z, into one flag byte each (bit0: known && v >= thr,
+// bit1: known && v <= thr, bit2: known).  The thread-per-voxel version above re-reads every
+// point 8..27 times with a stride of s elements between lanes (3.0 ms for 256 x 32^3 voxels).
+constexpr int SUB_TJ = 8, SUB_TK = 32;
+
+__global__ __launch_bounds__(SUB_TJ * SUB_TK) void mise_subdivide_lds_kernel(
+    int R1, int res0, int depth, int l, double thr, size_t n_per, size_t v_per,
+    const float *__restrict__ values, unsigned char *__restrict__ pstate,
+    unsigned char *__restrict__ vstate) {
+  extern __shared__ unsigned char flags[];
+  const int nl = res0 << l;
+  const int s = 1 << (depth - l);
+  const int tiles_k = (nl + SUB_TK - 1) / SUB_TK, tiles_j = (nl + SUB_TJ - 1) / SUB_TJ;
+  const int tile = blockIdx.x;
+  const int vk0 = (tile % tiles_k) * SUB_TK, vj0 = ((tile / tiles_k) % tiles_j) * SUB_TJ;
+  const int vi = tile / (tiles_k * tiles_j);
+  const int kp = blockIdx.y;
+  unsigned char *ps = pstate + (size_t)kp * n_per;
+  const float *vals = values + (size_t)kp * n_per;
+  const int PK = SUB_TK * s + 1, PJ = SUB_TJ * s + 1;
+  const int x0 = vi * s, y0 = vj0 * s, z0 = vk0 * s;
+  for (int t = threadIdx.x; t < (s + 1) * PJ * PK; t += SUB_TJ * SUB_TK) {
+    const int c = t % PK, b = (t / PK) % PJ, a = t / (PK * PJ);
+    unsigned char f = 0;
+    if (y0 + b < R1 && z0 + c < R1) {
+      const size_t p = ((size_t)(x0 + a) * R1 + (y0 + b)) * R1 + (z0 + c);
+      if (ps[p] == 2) {
+        const double v = (double)vals[p];
+        f = 4 | (v >= thr ? 1 : 0) | (v <= thr ? 2 : 0);  // mise.pyx:225,227
+      }
+    }
+    flags[t] = f;
+  }
+  __syncthreads();
+  const int tk = threadIdx.x % SUB_TK, tj = threadIdx.x / SUB_TK;
+  const int vk = vk0 + tk, vj = vj0 + tj;
+  if (vk >= nl || vj >= nl) return;
+  unsigned char *vs = vstate + (size_t)kp * v_per + vstate_offset(res0, l);
+  const size_t e = ((size_t)vi * nl + vj) * nl + vk;
+  if (vs[e] != 1) return;  // not a leaf (mise.pyx:236,245)
+  unsigned any = 0;
+  for (int a = 0; a <= s; ++a)
+    for (int b = 0; b <= s; ++b)
+      for (int c = 0; c <= s; ++c)
+        any |= flags[(a * PJ + tj * s + b) * PK + tk * s + c];
+  if ((any & 3) != 3) return;
+  vs[e] = 2;  // subdivide_voxel (:253-283)
+  if (l + 1 < depth) {
+    unsigned char *vc = vstate + (size_t)kp * v_per + vstate_offset(res0, l + 1);
+    const int nc = nl * 2;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 2; ++c)
+          vc[((size_t)(2 * vi + a) * nc + (2 * vj + b)) * nc + (2 * vk + c)] = 1;
+  }
+  const int h = s >> 1;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b)
+      for (int c = 0; c < 3; ++c) {
+        const size_t p = ((size_t)(x0 + a * h) * R1 + (y0 + tj * s + b * h)) * R1 + (z0 + tk * s + c * h);
+        if (ps[p] == 0) ps[p] = 1;  // only add new grid points (:281-283)
+      }
+}
+
 // Forward fill along one axis (mise.pyx:142-163).  Thread per line.
 // axis 0: lines indexed by (j,k) run along i, etc.  `valid` = pstate >= 2.
 __global__ void mise_fill_kernel(int R1, int axis, size_t n_per, float *__restrict__ values,
@@ -410,6 +476,16 @@ RFD_API int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
   // round, so they cannot split until the next update (mise.pyx:239-251)
   for (int l = depth - 1; l >= 0; --l) {
     const size_t nvox = cube((size_t)res0 << l);
+    const int sl = 1 << (depth - l), nl = res0 << l;
+    if (sl <= 4) {
+      const unsigned tiles = (unsigned)(ceil_div(nl, SUB_TK) * ceil_div(nl, SUB_TJ) * nl);
+      const size_t lds = (size_t)(sl + 1) * (SUB_TJ * sl + 1) * (SUB_TK * sl + 1);
+      hipLaunchKernelGGL(mise_subdivide_lds_kernel, dim3(tiles, K), dim3(SUB_TJ * SUB_TK), lds,
+                         (hipStream_t)stream, R1, res0, depth, l, threshold, n_per, v_per, values,
+                         pstate, vstate);
+      RFD_CHECK_LAUNCH();
+      continue;
+    }
     hipLaunchKernelGGL(mise_subdivide_kernel, dim3((unsigned)((nvox + 255) / 256), K), dim3(256), 0,
                        (hipStream_t)stream, R1, res0, depth, l, threshold, n_per, v_per, values,
                        pstate, vstate);

@@ -27,26 +27,26 @@ def marching_cubes_batch(grids, threshold, pad_value=-1e6, return_flat=False):
     dev = grids.device
     D = n + 2
     per = D * D * D
-    ebits = torch.empty(K * per, dtype=torch.uint8, device=dev)
-    vcount = torch.empty(K * per, dtype=torch.int32, device=dev)
-    tcount = torch.empty(K * per, dtype=torch.int32, device=dev)
+    nblk = _lib.lib().rfd_mc_blocks(n)
+    code = torch.empty(K * per, dtype=torch.uint8, device=dev)
+    sums = torch.empty(2, K * nblk, dtype=torch.int32, device=dev)          # vertices / triangles
     _call("rfd_mc_classify", dev, K, n, float(pad_value), float(threshold), grids.data_ptr(),
-          ebits.data_ptr(), vcount.data_ptr(), tcount.data_ptr())
-    vinc = torch.cumsum(vcount, 0, dtype=torch.int32)
-    tinc = torch.cumsum(tcount, 0, dtype=torch.int32)
-    vbase = vinc - vcount
-    tbase = tinc - tcount
+          code.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr())
+    # one 1-D scan over both rows (the 2-row innermost-dim scan kernel is ~70x slower)
+    flat = torch.cumsum(sums.view(-1), 0, dtype=torch.int32)
+    inc = flat.view(2, -1) - torch.stack([flat.new_zeros(()), flat[K * nblk - 1]]).unsqueeze(1)
+    base = inc - sums
     # per-proposal boundaries + totals: one small D2H copy
-    ends = torch.arange(1, K + 1, device=dev) * per - 1
-    bounds = torch.stack([vinc[ends], tinc[ends]]).cpu()
+    bounds = inc[:, nblk - 1::nblk].cpu()
     vend = [0] + bounds[0].tolist()
     tend = [0] + bounds[1].tolist()
     nv, nt = vend[-1], tend[-1]
     verts = torch.empty(max(nv, 1), 3, dtype=torch.float64, device=dev)
     tris = torch.empty(max(nt, 1), 3, dtype=torch.int32, device=dev)
     if nv:
+        vbase = torch.empty(K * per, dtype=torch.int32, device=dev)          # scratch
         _call("rfd_mc_emit", dev, K, n, float(pad_value), float(threshold), grids.data_ptr(),
-              ebits.data_ptr(), vbase.data_ptr(), tcount.data_ptr(), tbase.data_ptr(),
+              code.data_ptr(), base[0].data_ptr(), base[1].data_ptr(), vbase.data_ptr(),
               verts.data_ptr(), tris.data_ptr())
     if return_flat:
         return verts[:nv], tris[:nt], vend, tend
