@@ -187,13 +187,26 @@ int rfd_occ_decode_w8(int n_tiles, const float *pts, const int *tile_prop, const
  * pool_max (optional, [M / rows_per_group][N], zero-initialised by the caller): running
  * max(0, C) over the rows of each group = the encoder's max-pool + ReLU (layers.py:380-392)
  * fused into the epilogue; needs the row-owner kernel (M, N % 256, K % 128, rows_per_group % 64).
- * With pool_max, C may be NULL: the product is then only pooled, never written. */
+ * With pool_max, C may be NULL: the product is then only pooled, never written.
+ * pool_signed != 0: pool_max receives the plain max over the rows instead (the caller
+ * initialises it to -inf), for consumers that do not rectify (pointseg.py global feature). */
 size_t rfd_gemm_packed_bytes(int N, int K);
 int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, void *stream);
 int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *packed_w,
                    float *C, int ldc, const float *bias, const float *gbias,
                    int rows_per_group, const float *R, int ldr, int relu_in, int relu_out,
-                   int sa, int sw, float *pool_max, void *stream);
+                   int sa, int sw, float *pool_max, int pool_signed, void *stream);
+
+/* ---- first layer of the skip-propagation point encoder (csrc/pos_embed.hip) ------------
+ * fc_pos applied to cat([points, box feature]) * mask (skip_propagation.py:55-66,
+ * layers.py:364-366), with the per-proposal share hoisted out by the caller:
+ *   out[r][n] = bias[n] + mask[r] * (sum_{j<d} x[r][j] W[n][j] + group[r / rows_per_group][n])
+ * x [M][ldx] (first d <= 8 columns), mask [M], W [N][ldw] (first d columns), bias [N],
+ * group [M / rows_per_group][N] = box_feature . W[:, d:]^T, out [M][ldo] (may be a column
+ * window of a wider row-major buffer).  N % 4 == 0, ldo % 4 == 0. */
+int rfd_pos_embed(int M, int N, int d, const float *x, int ldx, const float *mask,
+                  const float *W, int ldw, const float *bias, const float *group,
+                  int rows_per_group, float *out, int ldo, void *stream);
 
 /* ---- one ResnetBlockFC of the point encoder, fused (csrc/resblock.hip) ----------------
  * Replaces ResnetBlockFC.forward (models/iscnet/modules/layers.py:39-48) inside

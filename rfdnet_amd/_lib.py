@@ -45,12 +45,13 @@ SIGNATURES = {
     "rfd_points_in_boxes": [_i, _i, _i, _i, _f, _f, _f, _f],
     "rfd_nms3d": [_i, _i, C.c_double, _i, _i, _f, _f, _f, _f, _f, _f],
     "rfd_gemm_pack_w": [_i, _i, _i, _f, _f, _f],
-    "rfd_gemm_f16x3": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _i, _i, _i, _f, _f],
+    "rfd_gemm_f16x3": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _i, _i, _i, _f, _i, _f],
     "rfd_resblock_pack": [_i, _i, _f, _f, _f, _i, _i, _f, _f],
     "rfd_resblock_f16x3": [_i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _f],
     "rfd_mc_classify": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f],
     "rfd_mc_emit": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f, _f, _f, _f],
     "rfd_mc_blocks": [_i],
+    "rfd_pos_embed": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f],
 }
 _RESTYPES = {
     "rfd_last_error_string": C.c_char_p,

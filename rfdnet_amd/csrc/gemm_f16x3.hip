@@ -78,6 +78,7 @@ struct Args {
   int relu_in, relu_out;
   float a_scale, out_scale;     // 2^sa, 2^-(sa+sw)
   float *pool;                  // [M/rows_per_group][N] running max(0, C) per group, or null (row-owner kernel)
+  int pool_signed;              // pool holds the plain max (caller initialises it to -inf) instead of max(0, C)
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
@@ -287,7 +288,8 @@ __device__ __forceinline__ void rows_epilogue(const Args &g, unsigned char *smem
           for (int e = 0; e < 4; ++e) v[e] = acc[4 * p + bb][4 * q + e];
           *reinterpret_cast<f32x4 *>(tr + n * 128 + ((chunk ^ n) * 4)) = v;
         }
-      f32x4 pmax = {0.f, 0.f, 0.f, 0.f};
+      const float pinit = g.pool_signed ? -__builtin_inff() : 0.f;
+      f32x4 pmax = {pinit, pinit, pinit, pinit};
 #pragma unroll 8
       for (int j = 0; j < 16; ++j) {
         const int row = 2 * j + rsel;
@@ -312,7 +314,15 @@ __device__ __forceinline__ void rows_epilogue(const Args &g, unsigned char *smem
         for (int e = 0; e < 4; ++e) {
           const float other = __shfl_xor(pmax[e], 32);
           const float v = other > pmax[e] ? other : pmax[e];
-          if (rsel == 0 && v > 0.f) atomicMax(pp + e, __float_as_int(v));
+          // non-negative floats order like their bit patterns as signed ints, negative ones in
+          // reverse as unsigned ints; each atomic is a no-op against a stored value of the other sign
+          if (rsel == 0) {
+            if (v > 0.f) atomicMax(pp + e, __float_as_int(v));
+            else if (g.pool_signed) {
+              if (v == 0.f) atomicMax(pp + e, 0);          // +-0 -> +0
+              else atomicMin(reinterpret_cast<unsigned *>(pp + e), __float_as_uint(v));
+            }
+          }
         }
       }
     }
@@ -497,7 +507,7 @@ RFD_API int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, 
 RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *packed_w,
                            float *C, int ldc, const float *bias, const float *gbias,
                            int rows_per_group, const float *R, int ldr, int relu_in, int relu_out,
-                           int sa, int sw, float *pool_max, void *stream) {
+                           int sa, int sw, float *pool_max, int pool_signed, void *stream) {
   if (M <= 0) return 0;
   if (!C && !pool_max) {
     rfd_set_error("rfd_gemm_f16x3: C == NULL without pool_max", hipErrorInvalidValue);
@@ -513,6 +523,7 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
   g.M = M; g.N = N; g.K = K; g.relu_in = relu_in; g.relu_out = relu_out;
   g.a_scale = ldexpf(1.f, sa); g.out_scale = ldexpf(1.f, -(sa + sw));
   g.pool = pool_max;
+  g.pool_signed = pool_signed;
   g.gbias_stride = N;
   const bool aligned = !(ldc & 3) && !(ldr & 3) && !((uintptr_t)C & 15) && !((uintptr_t)R & 15) &&
                        !((uintptr_t)bias & 15) && !((uintptr_t)gbias & 15);

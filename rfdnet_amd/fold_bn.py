@@ -36,16 +36,17 @@ def folded(layer, bn=None):
     return W, b
 
 
-def linear_rows_pooled(x, W, b, rows_per_group):
-    """max over each group of rows_per_group rows of relu(x W^T + b) -> (M / rows_per_group, N),
+def linear_rows_pooled(x, W, b, rows_per_group, relu=True):
+    """max over each group of rows_per_group rows of relu?(x W^T + b) -> (M / rows_per_group, N),
     without writing the (M, N) product when the fused epilogue is available."""
     M, K = x.shape
     N = W.shape[0]
     if gemm.usable(M, N, K, x) and gemm.pool_usable(M, N, K, rows_per_group):
-        pool = torch.zeros(M // rows_per_group, N, device=x.device, dtype=x.dtype)
-        gemm.linear(x, W, bias=b, relu_out=True, rows_per_group=rows_per_group, pool=pool, store=False)
+        pool = torch.full((M // rows_per_group, N), 0.0 if relu else float('-inf'), device=x.device, dtype=x.dtype)
+        gemm.linear(x, W, bias=b, relu_out=relu, rows_per_group=rows_per_group, pool=pool, store=False,
+                    pool_signed=not relu)
         return pool
-    return linear_rows(x, W, b, relu=True).view(-1, rows_per_group, N).max(dim=1)[0]
+    return linear_rows(x, W, b, relu=relu).view(-1, rows_per_group, N).max(dim=1)[0]
 
 
 def linear_rows(x, W, b, relu=False, gbias=None, rows_per_group=1):

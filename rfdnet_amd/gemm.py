@@ -40,11 +40,12 @@ def _packed(weight):
 
 
 def linear(x, weight, bias=None, gbias=None, rows_per_group=1, residual=None, relu_in=False,
-           relu_out=False, out=None, pool=None, store=True):
+           relu_out=False, out=None, pool=None, store=True, pool_signed=False):
     """x (M,K) fp32 rows (row stride >= K allowed), weight (N,K) -> (M,N).
     pool: optional (M / rows_per_group, N) ZERO-initialised tensor that receives
     max(0, out) over the rows of every group (fused max-pool + ReLU); with store=False the
-    product itself is not written (returns None)."""
+    product itself is not written (returns None).  pool_signed: the pool (initialised to -inf
+    by the caller) receives the plain max instead."""
     M, K = x.shape
     N = weight.shape[0]
     assert usable(M, N, K, x)
@@ -63,7 +64,7 @@ def linear(x, weight, bias=None, gbias=None, rows_per_group=1, residual=None, re
             gbias.data_ptr() if gbias is not None else None, int(rows_per_group),
             residual.data_ptr() if residual is not None else None, ldr,
             int(relu_in), int(relu_out), SA, sw, pool.data_ptr() if pool is not None else None,
-            _lib.current_stream())
+            int(pool_signed), _lib.current_stream())
     _lib.check(rc, "rfd_gemm_f16x3")
     return out
 

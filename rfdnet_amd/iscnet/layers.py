@@ -1,6 +1,7 @@
 """Small fully-connected building blocks used by the skip-propagation encoder
 (models/iscnet/modules/layers.py:5-48 ResnetBlockFC, :340-392 ResnetPointnet).
-Plain GEMMs: they stay on rocBLAS through torch."""
+forward() is the reference composition (training / oracle); forward_factored() is the
+inference path on the split-precision GEMM (csrc/gemm_f16x3.hip)."""
 import torch
 import torch.nn as nn
 
@@ -80,55 +81,71 @@ class ResnetPointnet(nn.Module):
                 net = resblock.forward(blk, net, g0, gs, T)
             net = self.pool(net.view(B, T, h), dim=1)
             return self.fc_c(self.actvn(net))
-        fast = gemm.usable(B * T, 2 * h, 2 * h, pos_term.view(B * T, -1)) and h % 128 == 0
+        M = B * T
+        fast = gemm.usable(M, h, 2 * h, x2) and h % 128 == 0
+        if not fast:                                                         # plain torch, same factoring
+            net = self.block_0(pos_term)
+            for i in range(1, 5):
+                blk = getattr(self, 'block_%d' % i)
+                pooled = torch.relu(self.pool(net, dim=1))                   # (B,h)
+                g0 = F.linear(pooled, blk.fc_0.weight[:, h:], blk.fc_0.bias)
+                gs = F.linear(pooled, blk.shortcut.weight[:, h:])
+                ax = torch.relu(net)
+                dx = blk.fc_1(torch.relu(F.linear(ax, blk.fc_0.weight[:, :h]) + g0.unsqueeze(1)))
+                net = F.linear(ax, blk.shortcut.weight[:, :h]) + gs.unsqueeze(1) + dx
+            return self.fc_c(self.actvn(self.pool(net, dim=1)))
 
-        def stacked(i):
-            """[fc_0 ; shortcut] weights of block i, split into the per-point and the
-            pooled column halves (cached per parameter version)."""
+        # Split-precision GEMM path.  A block is TWO GEMMs over one row-major buffer
+        # cat = [hidden | block input]:
+        #   hidden = fc_0(relu(input))                       A = cat[:, h:],  C = cat[:, :h]
+        #   out    = [fc_1 | shortcut](relu(cat))            A = cat (contiguous rows)
+        # i.e. the shortcut rides in the K loop of the second GEMM instead of being produced by
+        # the first one and re-read as a residual: -0.5 GB of traffic per block at M = 262 144 and
+        # no residual epilogue.  The max-pool over a proposal's points (+ the ReLU every consumer
+        # applies to it) is fused into the second GEMM's epilogue; the last block is only pooled.
+        def weights(i):
             blk = getattr(self, 'block_%d' % i)
-            key = (i, blk.fc_0.weight._version, blk.shortcut.weight._version, blk.fc_0.bias._version,
+            key = (blk.fc_0.weight._version, blk.fc_1.weight._version, blk.shortcut.weight._version,
                    blk.fc_0.weight.data_ptr())
             c = self.__dict__.setdefault('_stack_cache', {})
             if c.get(i, (None,))[0] != key:
-                w = torch.cat([blk.fc_0.weight, blk.shortcut.weight], 0).detach()
-                bias = torch.cat([blk.fc_0.bias, torch.zeros_like(blk.fc_0.bias)]).detach()
-                c[i] = (key, w[:, :h].contiguous(), w[:, h:].contiguous(), bias, w.contiguous())
-            return blk, c[i]
+                w0, ws = blk.fc_0.weight.detach(), blk.shortcut.weight.detach()
+                wide = i == 0                                   # block 0: all 2h input columns are per-point
+                first = (w0 if wide else w0[:, :h]).contiguous()
+                second = torch.cat([blk.fc_1.weight.detach(), ws if wide else ws[:, :h]], 1).contiguous()
+                c[i] = (key, first, second, None if wide else w0[:, h:].contiguous(),
+                        None if wide else ws[:, h:].contiguous())
+            return (blk,) + c[i][1:]
 
-        # block 0: both halves of its 2h-wide input are per-point
-        blk, (_, _, _, bias0, w_full) = stacked(0)
-        # the max-pool over a proposal's points (+ the ReLU every consumer applies to it) rides in
-        # the epilogue of each block's second GEMM
-        fuse_pool = fast and gemm.pool_usable(B * T, h, h, T)
-
-        def second(blk, both, last=False):
-            pooled = torch.zeros(B, h, device=both.device, dtype=both.dtype) if fuse_pool else None
-            out = gemm.linear(both[:, :h], blk.fc_1.weight, bias=blk.fc_1.bias, residual=both[:, h:],
-                              relu_in=True, rows_per_group=T, pool=pooled,
-                              store=not (last and fuse_pool))      # the last block is only pooled
-            return (out.view(B, T, h) if out is not None else None), pooled
-
-        pooled = None
-        if fast:
-            x2 = pos_term.view(B * T, 2 * h)
-            both = gemm.linear(x2, w_full, bias=bias0, relu_in=True)                       # (M,2h)
-            net, pooled = second(blk, both)
-        else:
-            net = self.block_0(pos_term)
-        for i in range(1, 5):
-            blk, (_, w_pt, w_pl, bias, _) = stacked(i)
+        fuse_pool = gemm.pool_usable(M, h, 2 * h, T)
+        cat = self.__dict__.pop('_cat0', None)
+        if cat is None or cat.shape[0] != M or cat.device != x2.device or cat.data_ptr() + 4 * h != x2.data_ptr():
+            cat = torch.empty(M, 3 * h, device=x2.device, dtype=x2.dtype)    # caller did not use input_buffer()
+            cat[:, h:] = x2
+        pooled, width = None, 3 * h
+        for i in range(5):
+            blk, w_first, w_second, w0_pool, ws_pool = weights(i)
+            g0 = gs = None
+            if i:
+                g0 = F.linear(pooled, w0_pool, blk.fc_0.bias)                # once per proposal
+                gs = F.linear(pooled, ws_pool, blk.fc_1.bias)
+            gemm.linear(cat[:, h:], w_first, bias=None if i else blk.fc_0.bias, gbias=g0, rows_per_group=T,
+                        relu_in=True, out=cat[:, :h])
+            last = i == 4
+            nxt = None if last and fuse_pool else torch.empty(M, 2 * h, device=cat.device, dtype=cat.dtype)
+            pooled = torch.zeros(B, h, device=cat.device, dtype=cat.dtype) if fuse_pool else None
+            gemm.linear(cat, w_second, bias=None if i else blk.fc_1.bias, gbias=gs, rows_per_group=T,
+                        relu_in=True, out=None if nxt is None else nxt[:, h:], pool=pooled,
+                        store=nxt is not None)
             if pooled is None:
-                pooled = torch.relu(self.pool(net, dim=1))                   # (B,h)
-            gb = F.linear(pooled, w_pl, bias)                                # (B,2h): once per proposal
-            pooled = None
-            if fast:
-                both = gemm.linear(net.view(B * T, h), w_pt, gbias=gb, rows_per_group=T, relu_in=True)
-                net, pooled = second(blk, both, last=(i == 4))
-            else:
-                both = F.linear(torch.relu(net), w_pt) + gb.unsqueeze(1)     # (B,T,2h)
-                dx = blk.fc_1(torch.relu(both[..., :h]))
-                net = both[..., h:] + dx
-        if pooled is not None:                                               # = relu(max over the points)
-            return self.fc_c(pooled)
-        net = self.pool(net, dim=1)
-        return self.fc_c(self.actvn(net))
+                pooled = torch.relu(self.pool(nxt[:, h:].reshape(B, T, h), dim=1))
+            cat = nxt
+        return self.fc_c(pooled)                                             # = fc_c(relu(max over the points))
+
+    def input_buffer(self, B, T, device):
+        """(B*T, 2*hidden) view for the fc_pos output that forward_factored can use in place
+        (it is the right-hand part of block 0's [hidden | input] buffer)."""
+        h = self.block_0.size_h
+        cat = torch.empty(B * T, 3 * h, device=device, dtype=torch.float32)
+        self.__dict__['_cat0'] = cat
+        return cat[:, h:]

@@ -153,7 +153,7 @@ class PointSeg(nn.Module):
         inp.transpose(1, 2); BatchNorms folded into the layers, the global-feature
         share of the head's first layer reduced to one vector per proposal, wide
         layers on the split-precision GEMM."""
-        from ..fold_bn import folded, linear_rows
+        from ..fold_bn import folded, linear_rows, linear_rows_pooled
         B, P, D = inp.shape
         enc = self.feat
         x = inp.reshape(B * P, D)
@@ -167,8 +167,7 @@ class PointSeg(nn.Module):
             h = torch.bmm(h.view(B, P, -1), trans_feat).reshape(B * P, -1)
         pointfeat = h
         h = linear_rows(pointfeat, *folded(enc.conv2, enc.bn2), relu=True)
-        h = linear_rows(h, *folded(enc.conv3, enc.bn3), relu=False)
-        g = h.view(B, P, -1).max(dim=1)[0]                                   # (B,1024)
+        g = linear_rows_pooled(h, *folded(enc.conv3, enc.bn3), P, relu=False)   # (B,1024), product never written
         # head conv1 on cat([global (1024, per proposal), pointfeat (64, per point)]) + bn1
         W, b = folded(self.conv1, self.bn1)
         c = self.__dict__.get('_head_split')

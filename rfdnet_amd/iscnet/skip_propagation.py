@@ -1,12 +1,13 @@
 """Skip propagation (generation path): group scan points around each predicted
 box, align to the box frame, mask with PointSeg and encode to the shape code
 (models/iscnet/modules/skip_propagation.py:13-82).  The K x 80 000 ball query
-(r = 1 m, 1024 samples) and the grouping are HIP kernels; the dense nets are
-torch/rocBLAS."""
+(r = 1 m, 1024 samples), the grouping, fc_pos (csrc/pos_embed.hip) and the wide
+layers (csrc/gemm_f16x3.hip) are HIP kernels."""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import pos_embed
 from ..pointnet2_ops.pointnet2_modules import STN_Group
 from .layers import ResnetPointnet
 from .pointseg import PointSeg
@@ -50,7 +51,13 @@ class SkipPropagation(nn.Module):
         d = inp.shape[2]
         box = box_feature.transpose(1, 2).contiguous().view(B * K, -1)          # (B*K,128)
         w = enc.fc_pos.weight
-        pos = F.linear(inp * maskf, w[:, :d], enc.fc_pos.bias)                  # (B*K,P,2h)
-        pos.addcmul_(maskf, F.linear(box, w[:, d:]).unsqueeze(1))               # one pass instead of mul + add
-        codes = enc.forward_factored(pos)
+        group = F.linear(box, w[:, d:])                                          # (B*K,2h): once per proposal
+        rows = inp.reshape(B * K * P, d)
+        pos = enc.input_buffer(B * K, P, rows.device)                            # (B*K*P,2h) window of block 0's buffer
+        if pos_embed.usable(rows, w, pos):
+            pos_embed.pos_embed(rows, maskf.view(-1), w, enc.fc_pos.bias, group, P, pos)
+        else:
+            tmp = F.linear(inp * maskf, w[:, :d], enc.fc_pos.bias)
+            pos.copy_(tmp.addcmul_(maskf, group.unsqueeze(1)).view(B * K * P, -1))
+        codes = enc.forward_factored(pos.view(B * K, P, -1))
         return codes.view(B, K, -1).transpose(1, 2)

@@ -93,3 +93,62 @@ def test_fused_group_max_pool(hip):
     with pytest.raises(Exception):
         gemm.linear(x[:, :96].contiguous(), w[:, :96].contiguous(), rows_per_group=T,
                     pool=torch.zeros(M // T, N, device="cuda"))
+
+
+def test_pos_embed_equals_composition(hip):
+    """fc_pos on cat([points, box feature]) * mask == the one-pass kernel, into a column window."""
+    from rfdnet_amd import pos_embed
+    g = torch.Generator(device="cuda").manual_seed(11)
+    G, P, d, F_, N = 6, 192, 4, 128, 1024
+    x = torch.randn(G * P, d, device="cuda", generator=g)
+    mask = (torch.rand(G * P, device="cuda", generator=g) > 0.4).float()
+    box = torch.randn(G, F_, device="cuda", generator=g)
+    W = torch.randn(N, d + F_, device="cuda", generator=g) * 0.2
+    b = torch.randn(N, device="cuda", generator=g)
+    full = torch.cat([x, box.repeat_interleave(P, 0)], 1) * mask[:, None]
+    want = torch.nn.functional.linear(full.double(), W.double(), b.double())
+    buf = torch.full((G * P, N + 512), 7.0, device="cuda")
+    out = buf[:, 512:]
+    group = torch.nn.functional.linear(box, W[:, d:])
+    pos_embed.pos_embed(x, mask, W, b, group, P, out)
+    assert (out.double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    assert torch.all(buf[:, :512] == 7.0)
+
+
+def test_skip_propagation_encoder_in_place_buffer(hip):
+    """forward_factored on the window handed out by input_buffer() == on a plain tensor == forward()."""
+    from rfdnet_amd import synthetic
+    from rfdnet_amd.iscnet.layers import ResnetPointnet
+    enc = ResnetPointnet(c_dim=512, dim=132, hidden_dim=512)
+    synthetic.load_seeded(enc, 9)
+    enc = enc.cuda().eval()
+    x = torch.randn(4, 256, 132, device="cuda")
+    with torch.no_grad():
+        plain = enc(x)
+        pos = enc.fc_pos(x)
+        a = enc.forward_factored(pos)
+        win = enc.input_buffer(4, 256, x.device)
+        win.copy_(pos.view(-1, 1024))
+        b = enc.forward_factored(win.view(4, 256, 1024))
+    assert torch.equal(a, b)
+    assert (plain - a).abs().max().item() < 1e-4 * max(1.0, plain.abs().max().item())
+
+
+def test_fused_group_max_pool_signed(hip):
+    """pool_signed: the plain max over each group's rows (columns that stay negative, zeros, mixed signs)."""
+    from rfdnet_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(8)
+    M, N, K, T = 1024, 512, 256, 128
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    w[7] = 0.0                                                        # a column of exact zeros
+    bias = torch.randn(N, device="cuda", generator=g) * 3.0 - 2.0     # many columns negative everywhere
+    bias[7] = 0.0
+    pool = torch.full((M // T, N), float("-inf"), device="cuda")
+    y = gemm.linear(x, w, bias=bias, rows_per_group=T, pool=pool, pool_signed=True)
+    want = y.view(M // T, T, N).max(dim=1)[0]
+    assert (want < 0).any() and (want > 0).any()
+    assert torch.equal(pool, want + 0.0)
+    pool2 = torch.full((M // T, N), float("-inf"), device="cuda")
+    assert gemm.linear(x, w, bias=bias, rows_per_group=T, pool=pool2, pool_signed=True, store=False) is None
+    assert torch.equal(pool2, pool)
