@@ -158,8 +158,11 @@ class Generator3D(object):
         v, f, vend, tend = marching_cubes_batch(grids, thr, pad_value=-1e6, return_flat=True)
         # generator.py:163-168 (the library's 0.5 offset is not present here):
         # undo padding, normalise to the unit cube, scale to the bounding box --
-        # once on the buffer holding all K meshes, then split into views
-        v = box_size * ((v - 1) / (n - 1) - 0.5)
+        # once on the buffer holding all K meshes, then split into views.  One pass over the
+        # 24 B/vertex buffer: box * ((v - 1) / (n - 1) - 0.5) = a * v + c (differs from the
+        # four-op form by rounding only, ~1e-16)
+        a = box_size / (n - 1)
+        v = torch.add(torch.tensor(-a - 0.5 * box_size, dtype=v.dtype), v, alpha=a)
         self.last_buffers = (v, f, vend, tend)
         return [Mesh(v[vend[k]:vend[k + 1]], f[tend[k]:tend[k + 1]]) for k in range(len(vend) - 1)]
 

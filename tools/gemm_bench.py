@@ -7,7 +7,8 @@ if os.environ.get("RFD_LIB"): _lib.LIB_PATH = os.environ["RFD_LIB"]
 from rfdnet_amd import gemm
 
 torch.manual_seed(0)
-for M, N, K, res in ((262144, 1024, 1024, False), (262144, 1024, 512, False), (262144, 512, 512, True),
+for M, N, K, res in ((262144, 512, 1536, False), (262144, 512, 1024, False), (262144, 512, 512, False),
+                     (262144, 1024, 1024, False), (262144, 1024, 512, False), (262144, 512, 512, True),
                      (262144, 128, 64, False), (262144, 1024, 128, False), (262144, 512, 64, False)):
     x = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") * 0.05
