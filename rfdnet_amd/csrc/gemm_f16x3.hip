@@ -265,9 +265,76 @@ __device__ __forceinline__ void wait_vm() {
 // row handles columns 4l..4l+3, so bias + group bias (never null here: the host passes a zero
 // vector for an absent one) are loaded once per pass.  16-byte chunks are XOR-swizzled by the
 // row (conflict-free on both sides, no padding).  Optional fused max-pool over the group.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  const float w = __int_as_float(o);
+  return w > v ? w : v;
+}
+
+// Pool-only epilogue (C == NULL, no residual).  In the accumulator layout a lane is a ROW of
+// the product (point lane & 31) and its 16 registers per block are columns, so the group max is
+// a cross-lane reduction: five DPP max steps per register (xor 1, xor 2, half-mirror, mirror,
+// row_bcast15) leave the max over the wave's 32 rows in lanes 16-31 / 48-63.  When the
+// workgroup's 256 rows lie in one group the eight waves then combine through LDS and thread c
+// finishes column c (bias, scale, ReLU, ONE device-scope atomic per column and workgroup);
+// otherwise every wave finishes its own columns.  The atomics cross the XCDs' private L2s and
+// were the limit of these launches (8.4 M per K = 128 layer), not the arithmetic.
+// max commutes with the monotone fma / ReLU, so the result is bit-identical to rows_epilogue's.
+__device__ __forceinline__ void pool_finish(const Args &g, float v, size_t grp, int c) {
+  float o = __builtin_fmaf(v, g.out_scale, g.bias[c] + g.gbias[grp * g.gbias_stride + c]);
+  if (g.relu_out) o = o > 0.f ? o : 0.f;
+  int *p = reinterpret_cast<int *>(g.pool + grp * g.N + c);
+  if (o > 0.f) atomicMax(p, __float_as_int(o));
+  else if (g.pool_signed) {
+    if (o == 0.f) atomicMax(p, 0);          // +-0 -> +0
+    else atomicMin(reinterpret_cast<unsigned *>(p), __float_as_uint(o));
+  }
+}
+
+__device__ __forceinline__ void pool_epilogue(const Args &g, unsigned char *smem, const f32x16 (&acc)[8], int wave,
+                                              int lane, int m0, int n0) {
+  const int j = lane & 15, half = lane >> 5;
+  const int col = (j & 3) + 8 * (j >> 2) + 4 * half;
+  const bool whole_wg = g.rows_per_group % RM == 0;     // uniform
+  float *red = reinterpret_cast<float *>(smem);          // [8 waves][256 columns]
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    float sel = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[b][r];
+      v = dpp_max<0xB1>(v);          // quad_perm [1,0,3,2]
+      v = dpp_max<0x4E>(v);          // quad_perm [2,3,0,1]
+      v = dpp_max<0x141>(v);         // row_half_mirror
+      v = dpp_max<0x140>(v);         // row_mirror: uniform over each 16-lane row
+      v = dpp_max<0x142, 0xA>(v);    // row_bcast15 into rows 1 and 3
+      sel = j == r ? v : sel;
+    }
+    if (lane & 16) {
+      if (whole_wg) red[wave * 256 + 32 * b + col] = sel;
+      else pool_finish(g, sel, (size_t)(m0 / g.rows_per_group), n0 + 32 * b + col);
+    }
+  }
+  if (whole_wg) {
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 256) {
+      float v = red[t];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) v = red[w * 256 + t] > v ? red[w * 256 + t] : v;
+      pool_finish(g, v, (size_t)((m0 - wave * 32) / g.rows_per_group), n0 + t);
+    }
+  }
+}
+
 template <bool HAS_RES>
 __device__ __forceinline__ void rows_epilogue(const Args &g, unsigned char *smem, const f32x16 (&acc)[8], int wave,
                                               int lane, int m0, int n0) {
+  if (!HAS_RES && !g.C) {
+    pool_epilogue(g, smem, acc, wave, lane, m0, n0);
+    return;
+  }
   const int half = lane >> 5, n = lane & 31;
   {
     float *tr = reinterpret_cast<float *>(smem + wave * 16384);

@@ -89,6 +89,12 @@ def test_fused_group_max_pool(hip):
     assert torch.equal(pool, want)
     r = ref(x, w, bias, None, 1, res, True, False)
     assert (y.double() - r).abs().max().item() < 2e-5 * max(1.0, r.abs().max().item())
+    # pool-only launch (no product written): the cross-lane epilogue gives the same bits
+    pool_only = torch.zeros(M // T, N, device="cuda")
+    assert gemm.linear(x, w, bias=bias, relu_in=True, relu_out=True, rows_per_group=T, pool=pool_only,
+                       store=False) is None
+    y2 = gemm.linear(x, w, bias=bias, relu_in=True, relu_out=True)
+    assert torch.equal(pool_only, y2.view(M // T, T, N).max(dim=1)[0])
     # shapes that only the tile kernel takes cannot pool: an error, not a silent skip
     with pytest.raises(Exception):
         gemm.linear(x[:, :96].contiguous(), w[:, :96].contiguous(), rows_per_group=T,
