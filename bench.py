@@ -135,7 +135,7 @@ class MeshSink(object):
 
     def push(self, v, f):
         """Queue the meshes of the scene just finished; the copy is STARTED by
-        start_pending() when the next scene launches its last (longest) decode:
+        start_pending() when the next scene launches its first (longest) decode:
         small kernels run 3-10x slower with a PCIe copy in flight (the
         multi-workgroup FPS, which exchanges 8-byte granules through memory every
         round, 70 % slower); the MFMA-bound decoder does not care."""
@@ -179,8 +179,9 @@ def run_scene(net, pc, sink):
         codes = net.object_codes(end_points, proposal_features, ids, pc)
         cls = net.cls_codes(end_points, ids)
         gen = net.completion.generator
-        # the previous scene's PCIe copy rides behind the last (longest) decode launch
-        gen.round_hook = lambda r, depth: sink.start_pending() if r == depth else None
+        # the previous scene's PCIe copy rides behind the first (longest) decode launch
+        # (releasing it behind the second one instead measures the same)
+        gen.round_hook = lambda r, depth: sink.start_pending() if r == 0 else None
         meshes = gen.generate_mesh(codes, cls)
     v, f, _, _ = gen.last_buffers                              # all K meshes: one vertex / one face buffer
     sink.push(v, f)
