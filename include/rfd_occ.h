@@ -127,7 +127,8 @@ int rfd_mise_scatter(int n_tiles, int res0, int depth, const int *tile_prop,
 int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
                        const float *values, unsigned char *pstate,
                        unsigned char *vstate, void *stream);
-/* to_dense (mise.pyx:133-163): forward-fill along x, then y, then z. */
+/* to_dense (mise.pyx:133-163): forward-fill along x, then y, then z.  pstate is working
+ * storage here: its content after the call is unspecified (only `values` is the result). */
 int rfd_mise_to_dense(int K, int res0, int depth, float *values,
                       unsigned char *pstate, void *stream);
 

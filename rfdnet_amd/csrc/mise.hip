@@ -415,19 +415,70 @@ __global__ void mise_fill_kernel(int R1, int axis, size_t n_per, float *__restri
   else { stride = 1; start = ((size_t)u * R1 + v) * R1; }                         // (i=u,j=v)
   float *vals = values + (size_t)kp * n_per;
   unsigned char *ps = pstate + (size_t)kp * n_per;
-  bool prev_valid = ps[start] >= 2;
-  float prev = vals[start];
-  for (int q = 1; q < R1; ++q) {
-    const size_t p = start + (size_t)q * stride;
-    const bool valid = ps[p] >= 2;
-    if (!valid && prev_valid) {
-      vals[p] = prev;
-      ps[p] = 3;
+  bool prev_valid = false;
+  float prev = 0.f;
+  // eight independent loads ahead of the serial carry (the stores never alias later loads)
+  for (int q0 = 0; q0 < R1; q0 += 8) {
+    float v[8];
+    unsigned char st[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool in = q0 + u < R1;
+      const size_t p = start + (size_t)(q0 + u) * stride;
+      st[u] = in ? ps[p] : 0;
+      v[u] = in ? vals[p] : 0.f;
     }
-    const bool now_valid = valid || prev_valid;
-    prev = now_valid ? vals[p] : prev;
-    prev_valid = now_valid;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (q0 + u >= R1) break;
+      const size_t p = start + (size_t)(q0 + u) * stride;
+      const bool valid = st[u] >= 2;
+      if (!valid && prev_valid) {
+        vals[p] = prev;
+        ps[p] = 3;
+      }
+      prev = valid ? v[u] : prev;
+      prev_valid = valid || prev_valid;
+    }
   }
+}
+
+// y then z fill of one x plane in LDS (the two later passes of to_dense only move data inside
+// a plane): the plane is read and written once, coalesced; a thread walks one line serially in
+// LDS (line strides R1 and 1 words, R1 odd: conflict-free).  States are not written back --
+// nothing reads them after to_dense.
+__global__ __launch_bounds__(256) void mise_fill_yz_kernel(int R1, size_t n_per,
+                                                           float *__restrict__ values,
+                                                           const unsigned char *__restrict__ pstate) {
+  extern __shared__ float plane_v[];                       // R1*R1 floats, then R1*R1 state bytes
+  const int n2 = R1 * R1;
+  unsigned char *plane_s = reinterpret_cast<unsigned char *>(plane_v + n2);
+  const size_t base = (size_t)blockIdx.y * n_per + (size_t)blockIdx.x * n2;
+  for (int t = threadIdx.x; t < n2; t += 256) {
+    plane_v[t] = values[base + t];
+    plane_s[t] = pstate[base + t];
+  }
+  __syncthreads();
+  for (int axis = 1; axis <= 2; ++axis) {
+    if ((int)threadIdx.x < R1) {
+      const int stride = axis == 1 ? R1 : 1;
+      const int start = axis == 1 ? (int)threadIdx.x : (int)threadIdx.x * R1;
+      bool prev_valid = false;
+      float prev = 0.f;
+      for (int q = 0; q < R1; ++q) {
+        const int p = start + q * stride;
+        const bool valid = plane_s[p] >= 2;
+        if (!valid && prev_valid) {
+          plane_v[p] = prev;
+          plane_s[p] = 3;
+        }
+        prev = valid ? plane_v[p] : prev;
+        prev_valid = valid || prev_valid;
+      }
+    }
+    __syncthreads();
+  }
+  for (int t = threadIdx.x; t < n2; t += 256) values[base + t] = plane_v[t];
 }
 
 // z-axis fill with a WAVE per line (lanes = k): coalesced, and the forward fill
@@ -569,13 +620,19 @@ RFD_API int rfd_mise_to_dense(int K, int res0, int depth, float *values,
   if (K <= 0) return 0;
   const int R1 = (res0 << depth) + 1;
   const size_t n_per = cube((size_t)R1);
-  for (int axis = 0; axis < 2; ++axis) {
+  const size_t plane_lds = (size_t)R1 * R1 * 5;
+  const bool fused = plane_lds <= 64 * 1024 && R1 <= 256;   // a whole x plane fits in LDS
+  for (int axis = 0; axis < (fused ? 1 : 2); ++axis) {
     hipLaunchKernelGGL(mise_fill_kernel, dim3(ceil_div(R1 * R1, 256), K), dim3(256), 0,
                        (hipStream_t)stream, R1, axis, n_per, values, pstate);
     RFD_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(mise_fill_z_kernel, dim3(ceil_div(R1 * R1, 4), K), dim3(256), 0,
-                     (hipStream_t)stream, R1, n_per, values, pstate);
+  if (fused)
+    hipLaunchKernelGGL(mise_fill_yz_kernel, dim3(R1, K), dim3(256), plane_lds, (hipStream_t)stream,
+                       R1, n_per, values, pstate);
+  else
+    hipLaunchKernelGGL(mise_fill_z_kernel, dim3(ceil_div(R1 * R1, 4), K), dim3(256), 0,
+                       (hipStream_t)stream, R1, n_per, values, pstate);
   RFD_CHECK_LAUNCH();
   return 0;
 }
