@@ -117,10 +117,12 @@ int rfd_mise_count(int K, int res0, int depth, const unsigned char *pstate,
 int rfd_mise_collect(int K, int res0, int depth, const unsigned char *pstate,
                      const int *offsets, int *cursors, float box_size,
                      float *pts, int *lin, void *stream);
-/* values[prop][lin] = logits[slot], pstate = known (mise.pyx:96-102) */
+/* values[prop][lin] = logits[slot], pstate = known (mise.pyx:96-102).  tile_src (optional):
+ * tile of `lin` holding this tile's lattice indices, for query lists shared by several
+ * proposals (round 0: every proposal asks for the same level-0 lattice). */
 int rfd_mise_scatter(int n_tiles, int res0, int depth, const int *tile_prop,
-                     const int *lin, const float *logits, float *values,
-                     unsigned char *pstate, void *stream);
+                     const int *tile_src, const int *lin, const float *logits,
+                     float *values, unsigned char *pstate, void *stream);
 /* One subdivide_voxels pass (mise.pyx:196-251): a leaf voxel below max depth
  * splits iff among the known points of its closed cube one has value >= thr
  * and one has value <= thr (both non-strict, :225-227). */

@@ -39,7 +39,7 @@ SIGNATURES = {
     "rfd_mise_init": [_i, _i, _i, _f, _f, _f],
     "rfd_mise_count": [_i, _i, _i, _f, _f, _f],
     "rfd_mise_collect": [_i, _i, _i, _f, _f, _f, _fl, _f, _f, _f],
-    "rfd_mise_scatter": [_i, _i, _i, _f, _f, _f, _f, _f, _f],
+    "rfd_mise_scatter": [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f],
     "rfd_mise_subdivide": [_i, _i, _i, C.c_double, _f, _f, _f, _f],
     "rfd_mise_to_dense": [_i, _i, _i, _f, _f, _f],
     "rfd_points_in_boxes": [_i, _i, _i, _i, _f, _f, _f, _f],

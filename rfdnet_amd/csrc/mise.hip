@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void mise_collect_kernel(
 }
 
 __global__ void mise_scatter_kernel(size_t n_per, const int *__restrict__ tile_prop,
+                                    const int *__restrict__ tile_src,
                                     const int *__restrict__ lin,
                                     const float *__restrict__ logits,
                                     float *__restrict__ values,
@@ -237,7 +238,8 @@ __global__ void mise_scatter_kernel(size_t n_per, const int *__restrict__ tile_p
   const int k = tile_prop[tile];
   if (k < 0) return;
   const size_t slot = (size_t)tile * RFD_OCC_TILE + threadIdx.x;
-  const int l = lin[slot];
+  // lin may be shared between proposals (tile_src: the tile of `lin` this tile's points come from)
+  const int l = lin[tile_src ? (size_t)tile_src[tile] * RFD_OCC_TILE + threadIdx.x : slot];
   if (l < 0) return;
   values[(size_t)k * n_per + l] = logits[slot];  // mise.pyx:101
   pstate[(size_t)k * n_per + l] = 2;             // :102 known = True
@@ -576,12 +578,13 @@ RFD_API int rfd_mise_collect(int K, int res0, int depth, const unsigned char *ps
 }
 
 RFD_API int rfd_mise_scatter(int n_tiles, int res0, int depth, const int *tile_prop,
-                             const int *lin, const float *logits, float *values,
-                             unsigned char *pstate, void *stream) {
+                             const int *tile_src, const int *lin, const float *logits,
+                             float *values, unsigned char *pstate, void *stream) {
   if (n_tiles <= 0) return 0;
   const int R1 = (res0 << depth) + 1;
   hipLaunchKernelGGL(mise_scatter_kernel, dim3(n_tiles), dim3(RFD_OCC_TILE), 0,
-                     (hipStream_t)stream, cube((size_t)R1), tile_prop, lin, logits, values, pstate);
+                     (hipStream_t)stream, cube((size_t)R1), tile_prop, tile_src, lin, logits, values,
+                     pstate);
   RFD_CHECK_LAUNCH();
   return 0;
 }

@@ -121,25 +121,35 @@ class Generator3D(object):
         thr = self.logit_threshold()
         n_queries, rounds = 0, 0
         while True:
-            _call("rfd_mise_count", dev, K, res0, depth, pstate.data_ptr(), counts.data_ptr())
-            cnt = counts.cpu().numpy().astype(np.int64)                      # the one sync per round
-            total = int(cnt.sum())
-            if total == 0:                                                   # generator.py:104
-                break
-            tiles = (cnt + TILE - 1) // TILE
-            offs = np.concatenate([[0], np.cumsum(tiles)[:-1]]) * TILE
-            n_tiles = int(tiles.sum())
-            tile_prop = torch.from_numpy(np.repeat(np.arange(K, dtype=np.int32), tiles)).to(dev)
-            offsets = torch.from_numpy(offs.astype(np.int32)).to(dev)
-            cursors = torch.zeros(K, dtype=torch.int32, device=dev)
-            pts = torch.zeros(n_tiles * TILE, 3, dtype=torch.float32, device=dev)
-            lin = torch.full((n_tiles * TILE,), -1, dtype=torch.int32, device=dev)
-            _call("rfd_mise_collect", dev, K, res0, depth, pstate.data_ptr(), offsets.data_ptr(),
-                  cursors.data_ptr(), float(box_size), pts.data_ptr(), lin.data_ptr())
+            shared = rounds == 0 and self._round0(res0, depth, box_size, K, dev)
+            if shared:
+                # round 0: every proposal asks for the same (res0+1)^3 level-0 lattice -- one
+                # cached query list (points, lattice indices, tile maps), no count / collect
+                # launches, no host sync, and the decoder reads 0.4 MB instead of K copies
+                pts, lin, tile_prop, tile_src, total = shared
+                n_tiles = tile_prop.numel()
+            else:
+                _call("rfd_mise_count", dev, K, res0, depth, pstate.data_ptr(), counts.data_ptr())
+                cnt = counts.cpu().numpy().astype(np.int64)                  # the one sync per round
+                total = int(cnt.sum())
+                if total == 0:                                               # generator.py:104
+                    break
+                tiles = (cnt + TILE - 1) // TILE
+                offs = np.concatenate([[0], np.cumsum(tiles)[:-1]]) * TILE
+                n_tiles = int(tiles.sum())
+                tile_prop = torch.from_numpy(np.repeat(np.arange(K, dtype=np.int32), tiles)).to(dev)
+                tile_src = None
+                offsets = torch.from_numpy(offs.astype(np.int32)).to(dev)
+                cursors = torch.zeros(K, dtype=torch.int32, device=dev)
+                pts = torch.zeros(n_tiles * TILE, 3, dtype=torch.float32, device=dev)
+                lin = torch.full((n_tiles * TILE,), -1, dtype=torch.int32, device=dev)
+                _call("rfd_mise_collect", dev, K, res0, depth, pstate.data_ptr(), offsets.data_ptr(),
+                      cursors.data_ptr(), float(box_size), pts.data_ptr(), lin.data_ptr())
             if self.round_hook is not None:           # e.g. release a host copy behind the long decode
                 self.round_hook(rounds, depth)
-            logits = dec.decode_tiles(pts, tile_prop, table, fc_p_w)
-            _call("rfd_mise_scatter", dev, n_tiles, res0, depth, tile_prop.data_ptr(), lin.data_ptr(),
+            logits = dec.decode_tiles(pts, tile_prop, table, fc_p_w, tile_src=tile_src)
+            _call("rfd_mise_scatter", dev, n_tiles, res0, depth, tile_prop.data_ptr(),
+                  tile_src.data_ptr() if tile_src is not None else None, lin.data_ptr(),
                   logits.data_ptr(), values.data_ptr(), pstate.data_ptr())
             _call("rfd_mise_subdivide", dev, K, res0, depth, float(thr), values.data_ptr(),
                   pstate.data_ptr(), vstate.data_ptr())
@@ -148,6 +158,35 @@ class Generator3D(object):
         _call("rfd_mise_to_dense", dev, K, res0, depth, values.data_ptr(), pstate.data_ptr())
         self.stats = {'n_queries': n_queries, 'rounds': rounds}
         return values.view(K, R1, R1, R1)
+
+    def _round0(self, res0, depth, box_size, K, dev):
+        """The query list of MISE round 0 for K proposals: the list of ONE freshly initialised
+        proposal (built once per configuration by the ordinary count / collect kernels, so it is
+        bit-identical to what they would produce for every proposal) plus tile maps that make
+        all K proposals read it.  Returns (pts, lin, tile_prop, tile_src, K * points)."""
+        key = (res0, depth, float(box_size), K, str(dev))
+        c = self.__dict__.get('_round0_cache')
+        if c is None or c[0] != key:
+            R1 = (res0 << depth) + 1
+            ps = torch.empty(1, R1 ** 3, dtype=torch.uint8, device=dev)
+            vs = torch.empty(1, _lib.lib().rfd_mise_vstate_elems(res0, depth), dtype=torch.uint8, device=dev)
+            cnt = torch.empty(1, dtype=torch.int32, device=dev)
+            _call("rfd_mise_init", dev, 1, res0, depth, ps.data_ptr(), vs.data_ptr())
+            _call("rfd_mise_count", dev, 1, res0, depth, ps.data_ptr(), cnt.data_ptr())
+            n = int(cnt.item())
+            tiles_per = (n + TILE - 1) // TILE
+            pts = torch.zeros(tiles_per * TILE, 3, dtype=torch.float32, device=dev)
+            lin = torch.full((tiles_per * TILE,), -1, dtype=torch.int32, device=dev)
+            offsets = torch.zeros(1, dtype=torch.int32, device=dev)
+            cursors = torch.zeros(1, dtype=torch.int32, device=dev)
+            _call("rfd_mise_collect", dev, 1, res0, depth, ps.data_ptr(), offsets.data_ptr(),
+                  cursors.data_ptr(), float(box_size), pts.data_ptr(), lin.data_ptr())
+            torch.cuda.current_stream(dev).synchronize()       # the scratch tensors die with this frame
+            tile_prop = torch.arange(K, dtype=torch.int32, device=dev).repeat_interleave(tiles_per)
+            tile_src = torch.arange(tiles_per, dtype=torch.int32, device=dev).repeat(K)
+            c = (key, (pts, lin, tile_prop, tile_src, K * n))
+            self.__dict__['_round0_cache'] = c
+        return c[1]
 
     # ---- mesh extraction ------------------------------------------------------------
     def extract_meshes(self, grids):

@@ -58,7 +58,7 @@ def gpu_mise(hip, fields, res0, depth, thr):
             m = ok & (tp == k)
             assert m.sum() == cnt[k]
             logits[m] = fields[k](coords[m], R1 - 1).astype(np.float32)
-        hip.check(lib.rfd_mise_scatter(n_tiles, res0, depth, tile_prop.data_ptr(), lin.data_ptr(),
+        hip.check(lib.rfd_mise_scatter(n_tiles, res0, depth, tile_prop.data_ptr(), None, lin.data_ptr(),
                                        torch.from_numpy(logits).cuda().data_ptr(), values.data_ptr(),
                                        pstate.data_ptr(), st), "scatter")
         hip.check(lib.rfd_mise_subdivide(K, res0, depth, float(thr), values.data_ptr(), pstate.data_ptr(),
