@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_QUERY = 2 * 3 * 256 + 10 * 2 * 256 * 256 + 2 * 256        # 1 312 768
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, MI355X_MICROARCH.md
-TRAFFIC_BYTES_PER_QUERY = 20.9  # measured (PMC), see roofline.traffic_source
+TRAFFIC_BYTES_PER_QUERY = 14.6  # measured (PMC), see roofline.traffic_source
 
 
 def parse():
@@ -373,11 +373,11 @@ def main():
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_PEAK_TFLOPS,
                          # HBM bytes per launch: the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
-                         # rocprofv3 --pmc runs, profiles/r01_j_decoder_pmc.txt) give 20.9 B per query
-                         # point (16 B algorithmic); scaled to this run's average launch
+                         # rocprofv3 --pmc runs of this benchmark, profiles/r01_t_decoder_bench_pmc.txt)
+                         # give 14.6 B per query point; scaled to this run's average launch
                          "traffic": TRAFFIC_BYTES_PER_QUERY * dec_pts / dec_launches if dec_launches else None,
-                         "traffic_source": "20.9 B/query from rocprofv3 PMC passes on the same kernel "
-                                           "(profiles/r01_j_decoder_pmc.txt) x queries per launch",
+                         "traffic_source": "14.6 B/query from rocprofv3 PMC passes on the decoder launches of this "
+                                           "benchmark (profiles/r01_t_decoder_bench_pmc.txt) x queries per launch",
                          "launches": int(dec_launches),
                          "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
                          "algorithmic_flop_per_launch": dec_pts * FLOP_PER_QUERY / dec_launches if dec_launches else None,
