@@ -211,25 +211,6 @@ int rfd_pos_embed(int M, int N, int d, const float *x, int ldx, const float *mas
                   const float *W, int ldw, const float *bias, const float *group,
                   int rows_per_group, float *out, int ldo, void *stream);
 
-/* ---- one ResnetBlockFC of the point encoder, fused (csrc/resblock.hip) ----------------
- * Replaces ResnetBlockFC.forward (models/iscnet/modules/layers.py:39-48) inside
- * ResnetPointnet.forward (layers.py:364-392) for rows x (M, k_in):
- *   out = Ws relu(x) + W1 relu(W0 relu(x) + g0[m / rows_per_group]) + gs[m / rows_per_group]
- * with W0 = fc_0.weight[:, :k_in], Ws = shortcut.weight[:, :k_in] (row stride ld),
- * W1 = fc_1.weight (256 x 256); g0 / gs (groups x 256) carry the biases and the
- * pooled-context half of the block input (constant over a group's rows).
- * Split-precision f16 MFMA (hi*hi + hi*lo + lo*hi), weights scaled by 2^kw0 (W0) and
- * 2^kw1 (Ws, W1).  k_in = 256 | 512; M and rows_per_group multiples of 128. */
-#define RFD_RESBLOCK_HIDDEN 256
-#define RFD_RESBLOCK_TILE 128
-#define RFD_RESBLOCK_KA 4
-size_t rfd_resblock_packed_bytes(int k_in);
-int rfd_resblock_pack(int k_in, int ld, const float *fc0_w, const float *shortcut_w,
-                      const float *fc1_w, int kw0, int kw1, void *packed, void *stream);
-int rfd_resblock_f16x3(int M, int k_in, int rows_per_group, const float *x, const void *packed,
-                       const float *g0, const float *gs, float *out, int kw0, int kw1,
-                       void *stream);
-
 #ifdef __cplusplus
 }
 #endif

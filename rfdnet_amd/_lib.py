@@ -46,8 +46,6 @@ SIGNATURES = {
     "rfd_nms3d": [_i, _i, C.c_double, _i, _i, _f, _f, _f, _f, _f, _f],
     "rfd_gemm_pack_w": [_i, _i, _i, _f, _f, _f],
     "rfd_gemm_f16x3": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _i, _i, _i, _f, _i, _f],
-    "rfd_resblock_pack": [_i, _i, _f, _f, _f, _i, _i, _f, _f],
-    "rfd_resblock_f16x3": [_i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _f],
     "rfd_mc_classify": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f],
     "rfd_mc_emit": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f, _f, _f, _f],
     "rfd_mc_blocks": [_i],
@@ -59,8 +57,7 @@ _RESTYPES = {
     "rfd_device_status": C.c_int,
     "rfd_occ_packed_bytes": C.c_size_t,
 }
-_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i],
-             "rfd_resblock_packed_bytes": [_i]}
+_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i]}
 
 _lib = None
 

@@ -62,25 +62,10 @@ class ResnetPointnet(nn.Module):
         their per-point halves run as one GEMM.  `pos_term` = fc_pos output
         (B,T,2*hidden), passed in because its own input is factored by the caller."""
         import torch.nn.functional as F
-        from .. import gemm, resblock
+        from .. import gemm
         h = self.block_0.size_h
         B, T, _ = pos_term.shape
         x2 = pos_term.reshape(B * T, 2 * h)
-        if h == resblock.HIDDEN and resblock.usable(x2, T):
-            # one fused kernel per block (csrc/resblock.hip): fc_0, ReLU, fc_1 and the
-            # shortcut without any intermediate leaving the registers
-            blk = self.block_0
-            zero = torch.zeros(1, h, device=x2.device, dtype=x2.dtype)
-            net = resblock.forward(blk, x2, (zero + blk.fc_0.bias).contiguous(),
-                                   (zero + blk.fc_1.bias).contiguous(), B * T)
-            for i in range(1, 5):
-                blk = getattr(self, 'block_%d' % i)
-                pooled = torch.relu(self.pool(net.view(B, T, h), dim=1))                    # (B,h)
-                g0 = F.linear(pooled, blk.fc_0.weight[:, h:], blk.fc_0.bias)                # once per proposal
-                gs = F.linear(pooled, blk.shortcut.weight[:, h:], blk.fc_1.bias)
-                net = resblock.forward(blk, net, g0, gs, T)
-            net = self.pool(net.view(B, T, h), dim=1)
-            return self.fc_c(self.actvn(net))
         M = B * T
         fast = gemm.usable(M, h, 2 * h, x2) and h % 128 == 0
         if not fast:                                                         # plain torch, same factoring
