@@ -356,7 +356,7 @@ def main():
             "dtype": "f32 (point ops, MLPs); f16x3 split MFMA with f32 accumulate (decoder, fp32-class)"
                      if args.mode == "f16x3" else "f32; f16 MFMA decoder (throughput mode, NOT parity)",
             "data": "synthetic (seeded ScanNet-like scenes, seeded random-init weights)",
-            "config": {"workload": "configs[1]: single scene per GPU, %d points, 256 proposals, "
+            "config": {"workload": "configs[1]: one ScanNet-like scene per forward pass, %d points, 256 proposals, "
                                    "%d^3 MISE (res0=%d, steps=%d), meshes to host"
                                    % (args.points, args.resolution0 << args.upsampling_steps,
                                       args.resolution0, args.upsampling_steps),
