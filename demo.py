@@ -25,13 +25,17 @@ def main():
     ap.add_argument("--resolution_0", type=int, default=32)
     ap.add_argument("--upsampling_steps", type=int, default=0)          # ISCNet_test.yaml:62-63
     ap.add_argument("--selection", choices=["nms", "all", "objectness"], default="nms")
+    ap.add_argument("--mean_size_npz", type=str, default=None,
+                    help="class mean sizes (the reference's datasets/scannet/scannet_means.npz); default: "
+                         "$RFD_MEAN_SIZE_NPZ or that path relative to the working directory")
     args = ap.parse_args()
 
     from rfdnet_amd import io, synthetic
     from rfdnet_amd.iscnet.config import Config
     from rfdnet_amd.iscnet.network import ISCNet
 
-    cfg = Config({'generation': {'resolution_0': args.resolution_0, 'upsampling_steps': args.upsampling_steps}})
+    cfg = Config({'generation': {'resolution_0': args.resolution_0, 'upsampling_steps': args.upsampling_steps}},
+                 mean_size_arr=args.mean_size_npz)
     net = ISCNet(cfg)
     if args.weight:
         ckpt = torch.load(args.weight, map_location="cpu")

@@ -128,6 +128,8 @@ const char *rfd_last_error_string(void);
 /* Device-side status word of the persistent kernels (FPS exchange spin
  * limit).  Synchronises the device.  0 = OK. */
 int rfd_device_status(void);
+/* The same word after waiting for `stream` only (other streams keep running). */
+int rfd_stream_status(void *stream);
 /* "gfx950" etc. of the code object actually loaded. */
 const char *rfd_build_arch(void);
 

@@ -24,9 +24,10 @@ _f64p = C.POINTER(C.c_double)
 
 def build(force=False):
     """Compile liboracle.so with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "rfd_oracle.c")
+    deps = [os.path.join(_HERE, "rfd_oracle.c"),
+            os.path.join(os.path.dirname(_HERE), "rfdnet_amd", "csrc", "mc_tables.h")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
                           stdout=subprocess.DEVNULL)
@@ -339,3 +340,38 @@ class TorchExt(object):
 
     def group_points_grad(self, grad_out, idx, n):
         return self._t(group_points_grad(grad_out.numpy(), idx.numpy(), n))
+
+
+# ---- marching cubes (PyMCubes' algorithm restated; see rfd_oracle.c) --------------
+def marching_cubes(volume, isovalue):
+    """volume (nx,ny,nz) -> (vertices (nv,3) f64 in index coordinates, triangles (nt,3) i32),
+    with the library's vertex / triangle order.  The CALLER pads (generator.py:158-159)."""
+    g = np.ascontiguousarray(volume, dtype=np.float64)
+    nx, ny, nz = g.shape
+    fn = lib().oracle_marching_cubes
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, _f64p, C.c_double, _f64p, C.POINTER(C.c_long),
+                   _i32p, C.POINTER(C.c_long)]
+    nv, nt = C.c_long(0), C.c_long(0)
+    gp = g.ctypes.data_as(_f64p)
+    rc = fn(nx, ny, nz, gp, float(isovalue), None, C.byref(nv), None, C.byref(nt))
+    assert rc == 0, "oracle_marching_cubes: %d" % rc
+    v = np.empty((nv.value, 3), np.float64)
+    t = np.empty((nt.value, 3), np.int32)
+    rc = fn(nx, ny, nz, gp, float(isovalue), v.ctypes.data_as(_f64p), C.byref(nv),
+            t.ctypes.data_as(_i32p), C.byref(nt))
+    assert rc == 0
+    return v, t
+
+
+def extract_mesh(occ_hat, threshold_logit, padding=0.1):
+    """Generator3D.extract_mesh (generator.py:145-168) on one value grid: pad with -1e6,
+    marching cubes, `-0.5`, `-1`, `/(n-1)`, `box*(v-0.5)`."""
+    occ_hat = np.asarray(occ_hat, dtype=np.float64)
+    n = np.array(occ_hat.shape, dtype=np.float64)
+    padded = np.pad(occ_hat, 1, 'constant', constant_values=-1e6)
+    v, t = marching_cubes(padded, threshold_logit)
+    v = v - 0.5
+    v = v - 1
+    v = v / (n - 1)
+    v = (1 + padding) * (v - 0.5)
+    return v, t

@@ -746,3 +746,91 @@ ORACLE_API void oracle_chamfer_backward(int b, int n, int m, const float *xyz1, 
     }
   }
 }
+
+/* ======================================================================== */
+/* Marching cubes -- restatement of the algorithm of PyMCubes 0.1.2         */
+/* (requirements.txt:35; call site models/iscnet/modules/generator.py:157-161:
+ * `mcubes.marching_cubes(np.pad(occ_hat, 1, constant_values=-1e6), thr)`).
+ * The library is a pip dependency, NOT vendored under the reference, so this
+ * restates its published algorithm and is pinned by the meshes the reference
+ * ships under demo/outputs/scene0549_00 (written by that library through
+ * generator.py:157-183 and demo.py:283-287), fixture tests/golden/F_MC.npz:
+ *   - cells are walked x-major (x outermost, z innermost);
+ *   - a cell creates vertices only on the three edges meeting at its corner 6,
+ *     in the order edge 6 (x), edge 5 (y), edge 10 (z); the other nine edges'
+ *     vertices are shared from cells walked earlier (edges on the low faces of
+ *     the volume cannot be crossed here: the caller's padding shell is constant);
+ *   - then the cell's triangles in table order.  Corner numbering 0..7 =
+ *     (0,0,0),(1,0,0),(1,1,0),(0,1,0),(0,0,1),(1,0,1),(1,1,1),(0,1,1);
+ *   - vertex = (x2-x1)*(iso-f1)/(f2-f1)+x1 walking edge 6 from corner 6 to 7 and
+ *     edges 5 / 10 from corner 5 / 2 to corner 6; midpoint if f1 == f2.
+ * The demo meshes determine all of the above except the treatment of a value
+ * exactly equal to iso (taken as "below", `<=`) and the last bit of the double
+ * interpolation.  The 256-row table comes from rfdnet_amd/csrc/mc_tables.h
+ * (generated data: tools/gen_mc_tables.py; 189 rows are read back from the
+ * demo meshes in tests/test_mcubes_golden.py).
+ * grid: [nx][ny][nz] doubles (already padded by the caller).  Two-call protocol:
+ * verts == NULL -> only counts.  Returns 0.                                  */
+#include "../rfdnet_amd/csrc/mc_tables.h"
+
+ORACLE_API int oracle_marching_cubes(int nx, int ny, int nz, const double *g, double iso,
+                                     double *verts, long *n_verts, int *tris, long *n_tris) {
+  static const int cx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, cy[8] = {0, 0, 1, 1, 0, 0, 1, 1},
+                   cz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  static const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3},
+                   eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+  const size_t npt = (size_t)nx * ny * nz;
+  /* vertex index of the edge ENDING in a lattice point, per axis (-1 = none) */
+  int *vid = (int *)malloc(npt * 3 * sizeof(int));
+  if (!vid) return -1;
+  memset(vid, 0xff, npt * 3 * sizeof(int));
+  long nv = 0, nt = 0;
+#define G(i, j, k) g[((size_t)(i) * ny + (j)) * nz + (k)]
+  for (int i = 0; i < nx - 1; ++i)
+    for (int j = 0; j < ny - 1; ++j)
+      for (int k = 0; k < nz - 1; ++k) {
+        double v[8];
+        unsigned ci = 0;
+        for (int c = 0; c < 8; ++c) {
+          v[c] = G(i + cx[c], j + cy[c], k + cz[c]);
+          if (v[c] <= iso) ci |= 1u << c;
+        }
+        if (ci == 0 || ci == 255) continue;
+        const size_t far = ((size_t)(i + 1) * ny + (j + 1)) * nz + (k + 1);
+        /* new vertices: edges 6, 5, 10 */
+        for (int a = 0; a < 3; ++a) {
+          const int e = a == 0 ? 6 : a == 1 ? 5 : 10;
+          const int c1 = a == 0 ? 6 : ea[e], c2 = a == 0 ? 7 : eb[e];
+          if (((ci >> c1) & 1u) == ((ci >> c2) & 1u)) continue;
+          const double p1[3] = {i + cx[c1], j + cy[c1], k + cz[c1]};
+          const double p2[3] = {i + cx[c2], j + cy[c2], k + cz[c2]};
+          const double f1 = v[c1], f2 = v[c2];
+          const double x = (f2 == f1) ? (p2[a] + p1[a]) / 2
+                                      : (p2[a] - p1[a]) * (iso - f1) / (f2 - f1) + p1[a];
+          if (verts) {
+            double *o = verts + 3 * nv;
+            o[0] = p1[0]; o[1] = p1[1]; o[2] = p1[2];
+            o[a] = x;
+          }
+          vid[far * 3 + a] = (int)nv++;
+        }
+        for (int t = 0; t < MC_NTRI[ci]; ++t) {
+          for (int r = 0; r < 3; ++r) {
+            const int e = MC_TRI[ci][3 * t + r];
+            const int hx = i + (cx[ea[e]] > cx[eb[e]] ? cx[ea[e]] : cx[eb[e]]);
+            const int hy = j + (cy[ea[e]] > cy[eb[e]] ? cy[ea[e]] : cy[eb[e]]);
+            const int hz = k + (cz[ea[e]] > cz[eb[e]] ? cz[ea[e]] : cz[eb[e]]);
+            const int axis = cx[ea[e]] != cx[eb[e]] ? 0 : cy[ea[e]] != cy[eb[e]] ? 1 : 2;
+            const int id = vid[(((size_t)hx * ny + hy) * nz + hz) * 3 + axis];
+            if (id < 0) { free(vid); return -2; } /* crossed edge on a low face of the volume */
+            if (tris) tris[3 * nt + r] = id;
+          }
+          ++nt;
+        }
+      }
+#undef G
+  free(vid);
+  *n_verts = nv;
+  *n_tris = nt;
+  return 0;
+}

@@ -57,6 +57,7 @@ _RESTYPES = {
     "rfd_device_status": C.c_int,
     "rfd_occ_packed_bytes": C.c_size_t,
 }
+_INT_FNS = {"rfd_stream_status": [_f]}
 _SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i]}
 
 _lib = None
@@ -89,6 +90,10 @@ def lib():
             fn = getattr(l, name)
             fn.restype = rt
             fn.argtypes = []
+        for name, at in _INT_FNS.items():
+            fn = getattr(l, name)
+            fn.restype = C.c_int
+            fn.argtypes = at
         for name, at in _SIZE_FNS.items():
             fn = getattr(l, name)
             fn.restype = C.c_size_t
@@ -98,7 +103,7 @@ def lib():
 
 
 def exported_symbols():
-    return sorted(list(SIGNATURES) + list(_RESTYPES) + list(_SIZE_FNS))
+    return sorted(list(SIGNATURES) + list(_RESTYPES) + list(_SIZE_FNS) + list(_INT_FNS))
 
 
 def check(rc, what):
@@ -114,13 +119,23 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def device_status():
-    """Synchronises; raises if a persistent kernel flagged a problem."""
-    st = lib().rfd_device_status()
+def _raise_status(st):
     if st < 0:
         raise RfdHipError("rfd_device_status failed")
     if st & 1:
         raise RfdHipError("FPS inter-workgroup exchange timed out")
     if st & 2:
         raise RfdHipError("occupancy decoder: activation exceeded the f16 range")
+    if st & 4:
+        raise RfdHipError("split-precision GEMM: activation exceeded the f16 range")
     return st
+
+
+def device_status():
+    """Synchronises the DEVICE; raises if a persistent kernel flagged a problem."""
+    return _raise_status(lib().rfd_device_status())
+
+
+def stream_status():
+    """Waits for the current stream only, then reads the same status word."""
+    return _raise_status(lib().rfd_stream_status(current_stream()))

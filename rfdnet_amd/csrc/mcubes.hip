@@ -5,15 +5,23 @@
 // (models/iscnet/modules/generator.py:157-161).  PyMCubes 0.1.2 is a
 // third-party dependency that is not vendored in the reference: its published
 // algorithm (table-driven marching cubes, one shared vertex per crossed lattice
-// edge placed by linear interpolation, indexed triangles) is restated; vertex
-// and triangle ORDER are this implementation's own (parity unpinned, see
-// DESIGN.md).  The case table is derived, not recalled (tools/gen_mc_tables.py).
+// edge placed by linear interpolation, indexed triangles) is restated, and its
+// OUTPUT CONVENTIONS are read back from the meshes the reference ships under
+// demo/outputs/ (tests/golden/F_MC.npz, tests/test_mcubes_golden.py): the case
+// table (tools/gen_mc_tables.py), triangles in x-major cell order and table order,
+// vertices numbered by (high end point of their edge in x-major order, axis).
+// Given a grid this kernel emits the same vertex and face arrays as the library
+// (faces identical, vertices to double rounding).  Not observable in those meshes
+// and therefore an assumption: a value EXACTLY equal to the iso level counts as
+// below it (`<=`).
 //
 // All K proposals are processed by the same launches; the -1e6 padding shell is
 // virtual (never materialised).  Three passes over K*D^3 lattice points
 // (D = n + 2), workgroup = a run of MC_RUN consecutive points of one proposal.
 // The only per-point state kept in HBM is ONE byte (the cube index of the point's cell)
-// plus a sparse int32 vertex base for points that own a vertex; prefix sums are two-level
+// (the cell whose FAR corner, corner 6, is the point -- a point owns the vertices of the three
+// edges that END in it, see above) plus a sparse int32 vertex base for points that own a
+// vertex; prefix sums are two-level
 // (per-workgroup sums -> tiny scan by the caller -> in-workgroup scan recomputed where
 // needed), so no dense int32 count / scan arrays are written or read:
 //   classify : point -> code byte; workgroup -> (#vertices, #triangles)
@@ -39,10 +47,13 @@ constexpr int MC_BLOCK = 256;
 constexpr int MC_PTS = 4;                    // consecutive lattice points per thread
 constexpr int MC_RUN = MC_BLOCK * MC_PTS;     // points per workgroup = unit of the two-level scan
 
-// Smallest float >= iso: for a float v, ((double)v < iso) == (v < float_ceil(iso)).
-__device__ __forceinline__ float float_ceil(double iso) {
+// Largest float <= iso: for a float v, ((double)v <= iso) == (v <= float_floor(iso)).
+__device__ __forceinline__ float float_floor(double iso) {
   float t = (float)iso;
-  if ((double)t < iso) t = __uint_as_float(__float_as_uint(t) + (t >= 0.f ? 1 : -1));
+  if ((double)t > iso) {
+    if (t == 0.f) t = -0.f;  // step from +0 to the largest negative subnormal below
+    t = __uint_as_float(__float_as_uint(t) + (t > 0.f ? -1 : 1));
+  }
   return t;
 }
 
@@ -95,14 +106,16 @@ __device__ __forceinline__ int block_scan(int x, int *total) {
   return off + inc - x;
 }
 
-// crossed +x / +y / +z edges of the cell origin, from the cube index (corner 0 vs 1, 3, 4)
+// crossed edges ENDING in the cell's far corner (x: edge 6 = corners 7-6, y: edge 5 = 5-6,
+// z: edge 10 = 2-6), from the cube index
 __device__ __forceinline__ unsigned edge_bits(unsigned ci) {
-  return (((ci >> 1) ^ ci) & 1u) | ((((ci >> 3) ^ ci) & 1u) << 1) | ((((ci >> 4) ^ ci) & 1u) << 2);
+  const unsigned c6 = ci >> 6;
+  return (((ci >> 7) ^ c6) & 1u) | ((((ci >> 5) ^ c6) & 1u) << 1) | ((((ci >> 2) ^ c6) & 1u) << 2);
 }
 
-// code[point] = cube index of the cell whose origin is the point, over the padded lattice
-// extended by one more virtual padding layer (cells on the far faces see only padding:
-// index 255, no triangles, no edges -- the same result as "no such cell").
+// code[point] = cube index of the cell whose FAR corner is the point, over the padded lattice
+// extended by one more virtual padding layer (cells hanging over the near faces see only
+// padding: index 255, no triangles, no edges -- the same result as "no such cell").
 // A workgroup owns a run of MC_RUN consecutive points, four per thread: the 32 corner loads
 // of a thread are independent and the per-run scan covers 4x the points (these passes were
 // bound by workgroup latency x rounds, not by bandwidth).  In the emit kernels thread t owns
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(
   const int D = n + 2;
   const unsigned per = (unsigned)D * D * D;
   const int kp = blockIdx.y;
-  const float thr = float_ceil(iso);
+  const float thr = float_floor(iso);
   // only the run TOTALS are needed here, so lanes take consecutive points (coalesced loads)
   const unsigned e = blockIdx.x * MC_RUN + threadIdx.x;
   GridView G{grids + (size_t)kp * n * n * n, n, D, pad};
@@ -128,10 +141,10 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(
       const Point P(ep, D);
       float v[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] = G.at(P.i + cx[c], P.j + cy[c], P.k + cz[c]);
+      for (int c = 0; c < 8; ++c) v[c] = G.at(P.i - 1 + cx[c], P.j - 1 + cy[c], P.k - 1 + cz[c]);
       unsigned ci = 0;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) ci |= (v[c] < thr ? 1u : 0u) << c;
+      for (int c = 0; c < 8; ++c) ci |= (v[c] <= thr ? 1u : 0u) << c;
       code[(size_t)kp * per + ep] = (unsigned char)ci;
       cnt += __popc(edge_bits(ci)) | ((int)c_ntri[ci] << 16);
     }
@@ -190,14 +203,19 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_vertices_kernel(
     while (q--) b &= b - 1;          // drop the q lowest crossed edges
     const int a = __ffs(b) - 1;      // axis of this vertex
     const Point P(e0 + c, D);
-    const double f1 = (double)G.at(P.i, P.j, P.k);
-    const double f2 = (double)G.at(P.i + (a == 0), P.j + (a == 1), P.k + (a == 2));
-    // linear interpolation along the edge (x2 - x1 = 1)
-    const double mu = (f2 == f1) ? 0.5 : (iso - f1) / (f2 - f1);
+    const double fhi = (double)G.at(P.i, P.j, P.k);
+    const double flo = (double)G.at(P.i - (a == 0), P.j - (a == 1), P.k - (a == 2));
+    // the library's interpolation, `(x2 - x1) * (iso - f1) / (f2 - f1) + x1`, walks the x edge
+    // from its high end (edge 6 = corners 6 -> 7) and the y / z edges from their low end
+    // (edges 5 and 10 = corners 5 -> 6, 2 -> 6); equal up to the last bit of a double
+    const double xhi = (double)(a == 0 ? P.i : a == 1 ? P.j : P.k), xlo = xhi - 1.0;
+    const double x1 = a == 0 ? xhi : xlo, x2 = a == 0 ? xlo : xhi;
+    const double f1 = a == 0 ? fhi : flo, f2 = a == 0 ? flo : fhi;
+    const double x = (f2 == f1) ? (x2 + x1) / 2 : (x2 - x1) * (iso - f1) / (f2 - f1) + x1;
     double *o = verts + (size_t)(base + t) * 3;
-    o[0] = (double)P.i + (a == 0 ? mu : 0.0);
-    o[1] = (double)P.j + (a == 1 ? mu : 0.0);
-    o[2] = (double)P.k + (a == 2 ? mu : 0.0);
+    o[0] = a == 0 ? x : (double)P.i;
+    o[1] = a == 1 ? x : (double)P.j;
+    o[2] = a == 2 ? x : (double)P.k;
   }
 }
 
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_triangles_kernel(
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int ed = c_tri[cc][3 * q + r];
-      const unsigned op = ec + (unsigned)((c_owner[ed][0] * D + c_owner[ed][1]) * D + c_owner[ed][2]);
+      const unsigned op = (unsigned)((int)ec + (c_owner[ed][0] * D + c_owner[ed][1]) * D + c_owner[ed][2]);
       const unsigned ob = edge_bits(pc[op]);
       const int axis = c_owner[ed][3];
       idx[r] = pv[op] + __popc(ob & ((1u << axis) - 1u)) - v0;

@@ -52,4 +52,16 @@ RFD_API int rfd_device_status(void) {
   return (int)v;
 }
 
+// Same word, but waits only for `stream` (several scenes may be in flight on other streams).
+RFD_API int rfd_stream_status(void *stream) {
+  RfdWorkspace *ws;
+  if (rfd_get_workspace(&ws)) return -1;
+  unsigned v = 0;
+  if (hipMemcpyAsync(&v, ws->status, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+    return -3;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -2;
+  if (v) (void)hipMemsetAsync(ws->status, 0, sizeof(v), (hipStream_t)stream);
+  return (int)v;
+}
+
 RFD_API const char *rfd_build_arch(void) { return "gfx950"; }

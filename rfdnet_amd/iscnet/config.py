@@ -3,6 +3,7 @@ read (values = configs/config_files/ISCNet_test.yaml; dataset constants =
 configs/scannet_config.py:11-25).  The reference's CONFIG class (logging, save
 dirs, CUDA_VISIBLE_DEVICES) is out of scope."""
 import copy
+import os
 
 import numpy as np
 
@@ -34,19 +35,36 @@ DEFAULT_CONFIG = {
 }
 
 
+MEAN_SIZE_NPZ = os.path.join('datasets', 'scannet', 'scannet_means.npz')
+
+
 class ScannetConfig(object):
     """configs/scannet_config.py:11-25: 8 classes, 12 heading bins, 8 size
-    clusters.  mean_size_arr is read from datasets/scannet/scannet_means.npz in
-    the reference; that file is data, not code, so a user passes it in
-    (`mean_size_arr=`); the default is a neutral placeholder (only box decoding
-    in parse_predictions, a 'next' row, consumes it)."""
+    clusters.  The reference reads mean_size_arr from the DATA file
+    `datasets/scannet/scannet_means.npz` relative to the working directory
+    (scannet_config.py:21).  Same here: an explicit array or path wins
+    (`mean_size_arr=`), then $RFD_MEAN_SIZE_NPZ, then that relative path; if none
+    exists a neutral placeholder is used and `placeholder_sizes` is set --
+    parse_predictions (box decoding, empty-box removal, 3-D NMS: everything behind
+    `selection='nms'`) warns, because its boxes are then NOT the reference's."""
 
     def __init__(self, mean_size_arr=None):
         self.num_class = 8
         self.num_heading_bin = 12
         self.num_size_cluster = 8
-        self.mean_size_arr = (np.asarray(mean_size_arr, dtype=np.float64) if mean_size_arr is not None
-                              else np.full((8, 3), 0.8))
+        self.placeholder_sizes = False
+        if mean_size_arr is None:
+            for cand in (os.environ.get('RFD_MEAN_SIZE_NPZ'), MEAN_SIZE_NPZ):
+                if cand and os.path.exists(cand):
+                    mean_size_arr = cand
+                    break
+        if isinstance(mean_size_arr, (str, bytes, os.PathLike)):
+            mean_size_arr = np.load(mean_size_arr)['arr_0']
+        if mean_size_arr is None:
+            self.placeholder_sizes = True
+            mean_size_arr = np.full((8, 3), 0.8)
+        self.mean_size_arr = np.asarray(mean_size_arr, dtype=np.float64)
+        assert self.mean_size_arr.shape == (self.num_size_cluster, 3), self.mean_size_arr.shape
 
     def class2angle_cuda(self, pred_cls, residual, to_label_format=True):
         """scannet_config.py:55-63"""

@@ -138,6 +138,17 @@ class ISCNet(nn.Module):
         cls = self.cls_codes(end_points, ids)
         gen = self.completion.generator
         if return_grids:
-            return end_points, ids, gen.generate_grids(codes, cls)
-        meshes = gen.generate_mesh(codes, cls)
-        return end_points, ids, meshes
+            out = gen.generate_grids(codes, cls)
+        else:
+            out = gen.generate_mesh(codes, cls)
+        # FPS exchange time-outs and decoder f16 overflow are reported through a device status
+        # word, not through return codes (the kernels are asynchronous): never hand back results
+        # without reading it.  Waits for THIS stream only (several scenes may be in flight).
+        self.check_device_status(pc.device)
+        return end_points, ids, out
+
+    @staticmethod
+    def check_device_status(device):
+        from .. import _lib
+        with torch.cuda.device(device):
+            _lib.stream_status()

@@ -10,6 +10,8 @@ scan points per box (:186-197, libs.py:128-137) and a numpy greedy NMS
 and the two heavy parts are HIP kernels (csrc/boxes.hip); nothing leaves the
 device except the final list of proposal ids.
 """
+import warnings
+
 import numpy as np
 import torch
 
@@ -74,6 +76,10 @@ def parse_predictions(end_points, point_clouds, dataset_config, config=None):
     """-> (eval_dict {'pred_mask' (B,K) uint8 tensor}, parsed dict).  Device tensors."""
     cfg = dict(DEFAULT_EVAL_CONFIG)
     cfg.update(config or {})
+    if getattr(dataset_config, 'placeholder_sizes', False):
+        warnings.warn("parse_predictions: mean_size_arr is the PLACEHOLDER (datasets/scannet/scannet_means.npz "
+                      "not found and no mean_size_arr given): decoded boxes, empty-box removal and NMS differ "
+                      "from the reference's", RuntimeWarning, stacklevel=2)
     dev = end_points['center'].device
     center, size, angle = decode_boxes(end_points, dataset_config)
     B, K = angle.shape
@@ -96,7 +102,10 @@ def parse_predictions(end_points, point_clouds, dataset_config, config=None):
         raise NotImplementedError("2-D NMS (use_3d_nms: False) is not used by RfD-Net's configs")
     aabb = torch.cat([corners.min(dim=2)[0], corners.max(dim=2)[0]], -1).contiguous()    # (B,K,6)
     keep = torch.empty(B, K, dtype=torch.uint8, device=dev)
-    order = torch.argsort(obj_prob, dim=1, descending=True, stable=True).int().contiguous()
+    # nms.py:90-94: `I = np.argsort(score)`, candidates taken from the END: among equal scores the
+    # HIGHEST index goes first (what an ascending sort that keeps equal keys in index order gives;
+    # numpy's default sort does so for the short runs it finishes by insertion)
+    order = torch.flip(torch.argsort(obj_prob, dim=1, descending=False, stable=True), dims=[1]).int().contiguous()
     cls_i = pred_sem_cls.int().contiguous()
     valid = nonempty.contiguous()
     _call("rfd_nms3d", dev, B, K, float(cfg['nms_iou']), int(bool(cfg['use_old_type_nms'])),

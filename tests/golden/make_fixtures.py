@@ -11,7 +11,7 @@ Recipe = SURVEY.md Appendix A: bare namespace packages so models/__init__.py
 replaced by the CPU oracle, absent third-party deps stubbed, MISE built from
 the reference's mise.pyx with Cython in a scratch directory.
 
-Usage:  python tests/golden/make_fixtures.py [dec] [mise] [grid] [ops] [net] [gen]
+Usage:  python tests/golden/make_fixtures.py [dec] [mise] [grid] [ops] [net] [gen] [nms] [cd] [fit] [mc]
 """
 import importlib
 import os
@@ -467,6 +467,35 @@ def make_fit():
     for j in range(K):
         sav['verts_%d' % j] = verts[j]
     np.savez_compressed(os.path.join(HERE, "F_FIT.npz"), **sav)
+
+
+def make_mc():
+    """F_MC: the meshes the reference itself ships under demo/outputs/scene0549_00
+    (proposal_*_mesh.ply, written by Generator3D.extract_mesh -> PyMCubes 0.1.2 ->
+    trimesh export, demo.py:283-287; dense 32^3 grids, canonical coordinates) stored as data:
+    float32 vertices and int32 faces exactly as in the files, plus the raw bytes of one PLY
+    header.  They are the only marching-cubes output the reference holds."""
+    import glob
+    from rfdnet_amd import io as rio
+    out = {}
+    files = sorted(glob.glob(REF + '/demo/outputs/scene0549_00/proposal_*_mesh.ply'))
+    assert len(files) == 13
+    names = []
+    for f in files:
+        name = os.path.basename(f)[:-len('_mesh.ply')]
+        v, fc = rio.read_mesh_ply(f)
+        out[name + '_v'] = np.asarray(v, np.float32)
+        out[name + '_f'] = np.asarray(fc, np.int32)
+        names.append(name)
+    raw = open(files[0], 'rb').read()
+    out['ply_header'] = np.frombuffer(raw[:raw.index(b'end_header\n') + len(b'end_header\n')], np.uint8)
+    out['ply_header_of'] = np.array(os.path.basename(files[0]))
+    out['names'] = np.array(names)
+    npz = np.load(REF + '/demo/outputs/scene0549_00/000000_pred_confident_nms_bbox.npz')
+    for k in npz.files:                       # the reference-held box dump: keys / dtypes / shapes
+        out['bbox_' + k] = npz[k]
+    np.savez_compressed(os.path.join(HERE, 'F_MC.npz'), **out)
+    print('F_MC.npz', os.path.getsize(os.path.join(HERE, 'F_MC.npz')) // 1024, 'KiB', names)
 
 
 if __name__ == "__main__":

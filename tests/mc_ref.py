@@ -1,5 +1,7 @@
 """Independent numpy restatement of table-driven marching cubes (test helper).
-Produces a triangle soup from the DERIVED case table (tools/gen_mc_tables.py)."""
+Produces a triangle soup from the case table of tools/gen_mc_tables.py (no vertex sharing, no
+ordering: used for geometric / topological properties; the ORDERED indexed mesh of the library
+is oracle.marching_cubes, pinned by tests/test_mcubes_golden.py)."""
 import os
 import sys
 
@@ -28,7 +30,7 @@ def marching_cubes_soup(grid, iso, pad=-1e6):
         for j in range(D - 1):
             for k in range(D - 1):
                 v = [g[i + c[0], j + c[1], k + c[2]] for c in C]
-                ci = sum(1 << c for c in range(8) if v[c] < iso)
+                ci = sum(1 << c for c in range(8) if v[c] <= iso)
                 for t in tb[ci]:
                     P = []
                     for e in t:

@@ -185,7 +185,7 @@ def field_grid(n, fn):
     return fn(g, n - 1).reshape(n, n, n).astype(np.float32)
 
 
-def test_marching_cubes_matches_numpy_restatement_and_is_watertight(hip):
+def test_marching_cubes_matches_numpy_restatement_and_is_watertight(hip, oracle):
     from rfdnet_amd.iscnet.mcubes import marching_cubes_batch
     n = 12
     rng = np.random.default_rng(0)
@@ -193,13 +193,23 @@ def test_marching_cubes_matches_numpy_restatement_and_is_watertight(hip):
                       rng.normal(size=(n, n, n)).astype(np.float32),         # every case incl. ambiguous
                       np.full((n, n, n), -1, dtype=np.float32),              # empty
                       np.full((n, n, n), 1, dtype=np.float32)])              # solid: closed by the padding
+    onlevel = rng.normal(size=(n, n, n)).astype(np.float32)
+    onlevel[rng.random((n, n, n)) < 0.2] = 0.0                               # values ON the iso level
+    grids = np.concatenate([grids, onlevel[None]])
     out = marching_cubes_batch(torch.from_numpy(grids).cuda(), 0.0)
     for k in range(grids.shape[0]):
         v, f = out[k][0].cpu().numpy(), out[k][1].cpu().numpy()
+        # the oracle = the library's algorithm incl. its vertex / triangle ORDER (pinned by the
+        # reference's demo meshes, tests/test_mcubes_golden.py): identical index arrays
+        ov, of = oracle.marching_cubes(np.pad(grids[k].astype(np.float64), 1, constant_values=-1e6), 0.0)
+        assert np.array_equal(f, of), k
+        assert v.shape == ov.shape and (v.size == 0 or np.abs(v - ov).max() < 1e-12), k
         ref = np_marching_cubes_soup(grids[k], 0.0)
         assert f.shape[0] == ref.shape[0]
         if f.shape[0] == 0:
             continue
+        if k == grids.shape[0] - 1:
+            continue        # degenerate (zero-area) triangles at on-level points: soup checks do not apply
         assert canon(v[f]) == canon(ref)
         # shared vertices: every vertex is used, no duplicates
         assert len(np.unique(f)) == v.shape[0] and len(np.unique(np.round(v, 9), axis=0)) == v.shape[0]
@@ -215,8 +225,33 @@ def test_marching_cubes_matches_numpy_restatement_and_is_watertight(hip):
     assert 0.85 * 4 / 3 * np.pi * r ** 3 < vol < 1.05 * 4 / 3 * np.pi * r ** 3
 
 
+def test_marching_cubes_reproduces_the_reference_demo_meshes(hip):
+    """The 13 meshes the reference ships (demo/outputs/scene0549_00, F_MC.npz): value grids
+    rebuilt from them go through the HIP marching cubes + Generator3D.extract_meshes and must
+    give back the same FACE ARRAYS (order, indexing, rotation) and the same vertices
+    (float32-PLY precision; the reference's -1.5 transform)."""
+    import mc_golden as MG
+    from rfdnet_amd.iscnet.generator import Generator3D
+    z, names = MG.load()
+    grids = []
+    for nm in names:
+        u, base, axis, t, inside = MG.analyse(z[nm + "_v"], z[nm + "_f"])
+        grids.append(MG.rebuild_grid(base, axis, t, inside))
+    gen = Generator3D(None, threshold=0.5, resolution0=32, upsampling_steps=0, padding=0.1)
+    meshes = gen.extract_meshes(torch.from_numpy(np.stack(grids)).cuda())
+    worst = 0.0
+    for nm, m in zip(names, meshes):
+        v, f = m.vertices.cpu().numpy(), m.faces.cpu().numpy()
+        assert np.array_equal(f, z[nm + "_f"]), nm
+        err = np.abs(v - z[nm + "_v"].astype(np.float64)).max() * 31 / 1.1
+        worst = max(worst, err)
+        assert err < 2e-3, (nm, err)
+    print("HIP marching cubes vs reference demo meshes: faces identical, max vertex deviation %.2e cells" % worst)
+
+
 def test_generate_mesh_end_to_end_scaling(hip, onet_and_fixture):
-    """vertices land in the padded unit box of generator.py:163-168"""
+    """vertices land where generator.py:163-168 puts them: on edges of the lattice shifted by
+    -1.5 padded cells, inside [-0.55 (1 + 1/(n-1)), 0.55 (1 - 1/(n-1))]"""
     fx = onet_and_fixture
     onet = load_onet_seeded(make_onet(16, 1), fx)
     meshes = onet.generator.generate_mesh(torch.from_numpy(fx["codes"]).cuda(), None)
@@ -224,5 +259,8 @@ def test_generate_mesh_end_to_end_scaling(hip, onet_and_fixture):
     for m in meshes:
         v = m.vertices.cpu().numpy()
         assert v.shape[0] > 0 and m.faces.shape[1] == 3
-        assert v.min() >= -0.55 * (1 + 1 / 32) - 1e-9 and v.max() <= 0.55 * (1 + 1 / 32) + 1e-9
+        assert v.min() >= -0.55 * (1 + 1 / 32) - 1e-9 and v.max() <= 0.55 * (1 - 1 / 32) + 1e-9
+        u = (v / 1.1 + 0.5) * 32 + 1.5                       # n = 33 grid points per axis
+        onlat = np.abs(u - np.round(u)) < 1e-6
+        assert (onlat.sum(1) >= 2).all()
         assert int(m.faces.max()) < v.shape[0]

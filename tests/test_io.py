@@ -53,6 +53,29 @@ def test_mesh_ply_layout_matches_the_reference_export(tmp_path):
     np.testing.assert_array_equal(ff, f)
 
 
+def test_mesh_ply_header_equals_the_reference_held_file(tmp_path):
+    """F_MC.npz keeps the raw header bytes of demo/outputs/scene0549_00/proposal_107_mesh.ply and
+    its arrays: writing the same mesh must give the same file up to the free-text comment line."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "F_MC.npz"))
+    ref_head = bytes(z["ply_header"]).decode("ascii").split("\n")
+    name = str(z["ply_header_of"])[:-len("_mesh.ply")]
+    v, f = z[name + "_v"], z[name + "_f"]
+    p = tmp_path / "m.ply"
+    io.write_mesh_ply(str(p), v, f)
+    raw = open(p, "rb").read()
+    end = raw.index(b"end_header\n") + 11
+    head = raw[:end].decode("ascii").split("\n")
+    strip = lambda h: [l for l in h if not l.startswith("comment")]
+    assert strip(head) == strip(ref_head)
+    assert len(raw) == end + len(v) * 12 + len(f) * 13          # float xyz; uchar count + 3 int32
+    vv, ff = io.read_mesh_ply(str(p))
+    assert np.array_equal(vv, v) and np.array_equal(ff, f)
+    # the reference-held box dump: keys, dtypes, shapes (demo.py:319-324)
+    assert z["bbox_obbs"].dtype == np.float64 and z["bbox_obbs"].shape[1] == 7
+    assert z["bbox_proposal_map"].dtype == np.int64 and z["bbox_proposal_map"].shape == (z["bbox_obbs"].shape[0], 1)
+    assert sorted(int(n.split("_")[1]) for n in z["names"]) == sorted(z["bbox_proposal_map"][:, 0].tolist())
+
+
 def test_save_visualization_files(tmp_path):
     class M(object):
         vertices = np.zeros((3, 3))

@@ -1,6 +1,7 @@
-"""CPU: the DERIVED marching-cubes table (tools/gen_mc_tables.py ->
-rfdnet_amd/csrc/mc_tables.h).  PyMCubes is not vendored in the reference, so the
-table is pinned by what a correct table must satisfy."""
+"""CPU: the marching-cubes table (tools/gen_mc_tables.py -> rfdnet_amd/csrc/mc_tables.h):
+what any correct table must satisfy, and that the published triangle list in use cuts
+exactly the polygons the face-loop derivation traces.  The rows PyMCubes actually used are
+read back from the reference's demo meshes in tests/test_mcubes_golden.py."""
 import os
 import re
 
@@ -21,6 +22,21 @@ def test_committed_header_is_what_the_script_generates():
         flat = [int(x) for x in row.split(",")]
         want = [e for t in tb[c] for e in t]
         assert flat[:len(want)] == want and all(x == -1 for x in flat[len(want):])
+
+
+def test_classic_rows_triangulate_the_derived_polygons():
+    tb, dv = G.classic(), G.derive()
+    assert mc_ref.table() == tb
+    for case in range(256):
+        assert len(tb[case]) == len(dv[case])
+        assert G.boundary(tb[case]) == G.boundary(dv[case]), case      # same loops, same orientation
+
+
+def test_edge_owner_is_the_high_end_point():
+    for e, (dx, dy, dz, axis) in enumerate(G.edge_owner()):
+        a, b = G.EDGES[e]
+        hi = np.maximum(G.CORNERS[a], G.CORNERS[b])
+        assert tuple(hi - 1) == (dx, dy, dz) and G.CORNERS[a][axis] != G.CORNERS[b][axis]
 
 
 def test_each_case_cuts_exactly_the_sign_changing_edges():
