@@ -2,47 +2,70 @@
 """Contract benchmark: scenes/sec end-to-end reconstruction (ScanNet-like scene,
 80 000 points, 256 proposals, 64^3 MISE) on N MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: spawns its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one scene per GPU:
+A "step" is one pass of the hot path over one batch of scenes per GPU:
   backbone (FPS / ball query / grouping / three_nn HIP kernels + 1x1-conv MLPs)
   -> voting -> vote aggregation + proposal head -> all 256 proposals
   -> skip propagation (K x 80 000 ball query, PointSeg, ResnetPointnet)
   -> batched 64^3 MISE with the fused MFMA occupancy decoder
   -> batched marching cubes -> meshes copied to host memory.
-Scenes shard one per GPU (weak scaling); the only collective is the all-gather
-of a small per-rank statistics vector (+ the MAX-reduce of the elapsed time).
-Inputs (scenes, weights) are synthetic and seeded, resident in HBM before the
-timed region.  Prints ONE JSON line on rank 0.
+Scenes shard across GPUs (scene i -> rank i mod N, rfdnet_amd/sharding.py; weak scaling); the
+only collective is the all-gather of a small per-rank statistics vector.  Inputs (scenes,
+weights) are synthetic and seeded, resident in HBM before the timed region.  A scene that
+raises is counted as failed, the run goes on.  Prints ONE JSON line on rank 0.
+
+--config selects the workload (BASELINE.json `configs`):
+  headline (default)  configs[1]: 80 000 points, 256 proposals, 64^3 MISE
+  mise128             configs[4] per GPU: 128^3 MISE (resolution_0 32, upsampling_steps 2)
+  dense32             configs[0]: 40 000 points (sampled WITH replacement), dense 32^3 grid
+  stress              configs[2]: decoder only, 256 proposals x 262 144 query points
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from rfdnet_amd import sharding  # noqa: E402  (no torch.cuda use at import)
+
 FLOP_PER_QUERY = 2 * 3 * 256 + 10 * 2 * 256 * 256 + 2 * 256        # 1 312 768 (BASELINE.md §3)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA, MI355X_MICROARCH.md
-TRAFFIC_BYTES_PER_QUERY = 14.6  # measured (PMC), see roofline.traffic_source
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "decoder_traffic.json")
+
+CONFIGS = {
+    "headline": dict(points=80000, resolution0=32, upsampling_steps=1, raw=120000,
+                     name="configs[1]: one ScanNet-like scene per forward pass, %(points)d points, 256 proposals, "
+                          "%(res)d^3 MISE (res0=%(resolution0)d, steps=%(upsampling_steps)d), meshes to host"),
+    "mise128": dict(points=80000, resolution0=32, upsampling_steps=2, raw=120000,
+                    name="configs[4] on one GPU: %(points)d points, 256 proposals, %(res)d^3 MISE "
+                         "(res0=%(resolution0)d, steps=%(upsampling_steps)d) + marching cubes, meshes to host"),
+    "dense32": dict(points=40000, resolution0=32, upsampling_steps=0, raw=30000,
+                    name="configs[0] on the GPU: %(points)d points sampled with replacement from a %(raw)d-vertex "
+                         "scan, 256 proposals, dense %(resolution0)d^3 occupancy grid, meshes to host"),
+    "stress": dict(points=0, resolution0=0, upsampling_steps=0, raw=0,
+                   name="configs[2]: occupancy decoder stress, 256 proposals x 262 144 query points"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=80000)
-    ap.add_argument("--resolution0", type=int, default=32)
-    ap.add_argument("--upsampling-steps", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="headline")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--resolution0", type=int, default=None)
+    ap.add_argument("--upsampling-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the one-scene-at-a-time pass after the timed region")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="scenes reconstructed concurrently per GPU (one host thread + HIP stream + model "
                          "replica each); a step = one such batch")
@@ -51,26 +74,18 @@ def parse():
                          "and the ~300 small launches are shared by the batch)")
     ap.add_argument("--mode", choices=["f16x3", "f16x1"], default="f16x3",
                     help="decoder arithmetic; f16x3 is the parity mode (1e-4 on logits)")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    c = CONFIGS[args.config]
+    for k in ("points", "resolution0", "upsampling_steps"):
+        if getattr(args, k) is None:
+            setattr(args, k, c[k])
+    args.raw = c["raw"]
+    if args.config == "stress":
+        args.in_flight = 1
+    return args
 
 
-def build_net(args, device):
-    from rfdnet_amd import synthetic
-    from rfdnet_amd.iscnet.config import Config
-    from rfdnet_amd.iscnet.network import ISCNet
-    from rfdnet_amd.iscnet import occ_decoder
-    cfg = Config({'data': {'num_point': args.points},
-                  'generation': {'resolution_0': args.resolution0,
-                                 'upsampling_steps': args.upsampling_steps}})
-    net = ISCNet(cfg)
-    synthetic.load_seeded(net, seed=10)           # the reference's seed (ISCNet_test.yaml:5)
-    net = net.to(device).eval()
-    net.completion.decoder.mode = occ_decoder.MODE_F16X3 if args.mode == "f16x3" else occ_decoder.MODE_F16X1
-    return net
-
-
-import threading
-
+# ------------------------------------------------------------------ HIP backend ---
 DECODE_LOCK = threading.Lock()
 
 
@@ -82,6 +97,7 @@ class DecodeTimer(object):
     kernel's own (the same number rocprofv3's kernel trace reports)."""
 
     def __init__(self, dec):
+        import torch
         self.dec = dec
         self.records = []
         self.enabled = False
@@ -100,26 +116,9 @@ class DecodeTimer(object):
             return out
         dec.decode_tiles = wrapped
 
-    def intervals(self, base):
-        """[(start_ms, end_ms, points)] of every recorded launch relative to `base`."""
-        return [(base.elapsed_time(e0), base.elapsed_time(e1), n) for n, e0, e1 in self.records]
-
-
-def union_ms(intervals):
-    """Length of the union of [start, end] intervals: with several scenes in flight
-    two decoder launches can be resident at once; the time 'the decoder' runs is the
-    union, not the sum, of their spans."""
-    tot, cur_s, cur_e = 0.0, None, None
-    for s0, e0, _ in sorted(intervals):
-        if cur_e is None or s0 > cur_e:
-            if cur_e is not None:
-                tot += cur_e - cur_s
-            cur_s, cur_e = s0, e0
-        else:
-            cur_e = max(cur_e, e0)
-    if cur_e is not None:
-        tot += cur_e - cur_s
-    return tot
+    def totals(self):
+        return (sum(e0.elapsed_time(e1) for _, e0, e1 in self.records), sum(n for n, _, _ in self.records),
+                len(self.records))
 
 
 class MeshSink(object):
@@ -129,9 +128,11 @@ class MeshSink(object):
     everything is drained before the clock stops."""
 
     def __init__(self, device):
+        import torch
         self.stream = torch.cuda.Stream(device)
         self.bufs = [[None, None], [None, None]]
         self.turn = 0
+        self.pending = None
 
     def push(self, v, f):
         """Queue the meshes of the scene just finished; the copy is STARTED by
@@ -142,7 +143,8 @@ class MeshSink(object):
         self.pending = (v, f)
 
     def start_pending(self):
-        if getattr(self, "pending", None) is None:
+        import torch
+        if self.pending is None:
             return
         v, f = self.pending
         self.pending = None
@@ -170,222 +172,368 @@ class MeshSink(object):
         self.stream.synchronize()
 
 
-def run_scene(net, pc, sink):
-    """ISCNet.generate(selection='all') stage by stage (network.py), with the
-    previous scene's mesh copy released behind the last decode launch."""
-    with torch.no_grad():
-        end_points, proposal_features = net.detect(pc)
-        ids = net.select_proposals(end_points, 'all', pc)
-        codes = net.object_codes(end_points, proposal_features, ids, pc)
-        cls = net.cls_codes(end_points, ids)
-        gen = net.completion.generator
-        # the previous scene's PCIe copy rides behind the first (longest) decode launch
-        # (releasing it behind the second one instead measures the same)
-        gen.round_hook = lambda r, depth: sink.start_pending() if r == 0 else None
-        meshes = gen.generate_mesh(codes, cls)
-    v, f, _, _ = gen.last_buffers                              # all K meshes: one vertex / one face buffer
-    sink.push(v, f)
-    return len(meshes), int(v.shape[0]), int(f.shape[0]), gen.stats.get('n_queries', 0)
+class HipBackend(object):
+    """The product path on one GPU: `in_flight` workers (model replica + HIP stream + mesh
+    sink + decoder timer each) over a pool of HBM-resident synthetic scenes."""
+
+    name = "hip"
+
+    def __init__(self, args, rank, local_rank, world):
+        import numpy as np
+        import torch
+        from rfdnet_amd import _lib, synthetic
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+        # RFD_BENCH_ONE_DEVICE=1: dry run of the N>1 code path on a 1-GPU box (all ranks
+        # on cuda:0, gloo for the statistics exchange) -- never used for reported numbers
+        self.one_dev = os.environ.get("RFD_BENCH_ONE_DEVICE") == "1"
+        dev_index = 0 if self.one_dev else local_rank
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
+        self.dist_backend = "gloo" if self.one_dev else "nccl"          # "nccl" = RCCL over xGMI
+        self.args, self.torch, self._lib = args, torch, _lib
+        self.S = max(1, args.in_flight)
+        self.NB = max(1, args.batch)
+        self.nets = [self._build_net() for _ in range(self.S)]
+        self.timers = [DecodeTimer(n.completion.decoder) for n in self.nets]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.S)]
+        self.sinks = [MeshSink(self.device) for _ in range(self.S)]
+        # scene pool: global scene id i -> seed 10 + (i mod pool), pool a multiple of the world size so
+        # that a rank always meets the same resident scenes (its residue class)
+        self.pool = world * 2 * self.S * self.NB
+        self.world = world
+        self.scenes = {}
+        for i in sharding.scene_ids_for_rank(self.pool, rank, world):
+            pc = synthetic.synthetic_scene(seed=10 + i, n_points=args.points, n_raw=args.raw)
+            self.scenes[i] = torch.from_numpy(pc).to(self.device)
+        torch.cuda.synchronize()
+
+    def _build_net(self):
+        from rfdnet_amd import synthetic
+        from rfdnet_amd.iscnet import occ_decoder
+        from rfdnet_amd.iscnet.config import Config
+        from rfdnet_amd.iscnet.network import ISCNet
+        a = self.args
+        cfg = Config({'data': {'num_point': a.points},
+                      'generation': {'resolution_0': a.resolution0, 'upsampling_steps': a.upsampling_steps}})
+        net = ISCNet(cfg)
+        synthetic.load_seeded(net, seed=10)           # the reference's seed (ISCNet_test.yaml:5)
+        net = net.to(self.device).eval()
+        net.completion.decoder.mode = occ_decoder.MODE_F16X3 if a.mode == "f16x3" else occ_decoder.MODE_F16X1
+        return net
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def worker_begin(self, w):
+        self.torch.cuda.set_device(self.device)
+        ctx = self.torch.cuda.stream(self.streams[w])
+        ctx.__enter__()
+        return ctx
+
+    def worker_end(self, w, ctx):
+        self.sinks[w].drain()
+        self.streams[w].synchronize()
+        ctx.__exit__(None, None, None)
+
+    def run_pass(self, w, ids):
+        """One forward pass over the scenes `ids` (ISCNet.generate(selection='all') stage by
+        stage, network.py) -> (meshes, vertices, triangles, query points)."""
+        torch = self.torch
+        net, sink = self.nets[w], self.sinks[w]
+        pc = torch.stack([self.scenes[i % self.pool] for i in ids])
+        with torch.no_grad():
+            end_points, proposal_features = net.detect(pc)
+            sel = net.select_proposals(end_points, 'all', pc)
+            codes = net.object_codes(end_points, proposal_features, sel, pc)
+            cls = net.cls_codes(end_points, sel)
+            gen = net.completion.generator
+            # the previous scene's PCIe copy rides behind the first (longest) decode launch
+            gen.round_hook = lambda r, depth: sink.start_pending() if r == 0 else None
+            meshes = gen.generate_mesh(codes, cls)
+            if self.args.upsampling_steps == 0:
+                sink.start_pending()
+        net.check_device_status(pc.device)                           # FPS time-out / f16 overflow -> raises
+        v, f, _, _ = gen.last_buffers                              # all K meshes: one vertex / one face buffer
+        sink.push(v, f)
+        return len(meshes), int(v.shape[0]), int(f.shape[0]), gen.stats.get('n_queries', 0)
+
+    def decode_totals(self):
+        tot = [0.0, 0, 0]
+        for tm in self.timers:
+            a = tm.totals()
+            tot = [x + y for x, y in zip(tot, a)]
+        return tot
+
+    def set_timing(self, on):
+        for tm in self.timers:
+            tm.enabled = on
+            if on:
+                tm.records = []
+
+    def final_check(self):
+        self._lib.device_status()
+
+    def kernel_name(self):
+        return "%s<%d>" % ("occ_decode8_kernel" if self.nets[0].completion.decoder.kernel == "w8"
+                           else "occ_decode_kernel", 3 if self.args.mode == "f16x3" else 1)
 
 
-def cpu_baseline(args, n_queries_per_scene, n_prop):
-    """The oracle (a port: the reference has NO CPU implementation of the point
-    ops) timed on this box's host cores on a bounded sample of the same scene,
-    extrapolated to one scene.  MLPs are NOT included (lower bound on CPU time)."""
-    from oracle import oracle
-    from rfdnet_amd import synthetic
-    oracle.build()
-    cores = oracle.num_threads()
-    pc = synthetic.synthetic_scene(seed=10, n_points=args.points)
-    xyz = np.ascontiguousarray(pc[None, :, :3])
-    t = {}
-    t0 = time.time()
-    i1 = oracle.furthest_point_sampling(xyz, 2048)
-    x1 = xyz[:, i1[0]]
-    i2 = oracle.furthest_point_sampling(x1, 1024); x2 = x1[:, i2[0]]
-    i3 = oracle.furthest_point_sampling(x2, 512); x3 = x2[:, i3[0]]
-    i4 = oracle.furthest_point_sampling(x3, 256); x4 = x3[:, i4[0]]
-    oracle.furthest_point_sampling(x2, 256)
-    t['fps'] = time.time() - t0
-    t0 = time.time()
-    idx1 = oracle.ball_query(x1, xyz, 0.2, 64)
-    idx2 = oracle.ball_query(x2, x1, 0.4, 32)
-    oracle.ball_query(x3, x2, 0.8, 16)
-    oracle.ball_query(x4, x3, 1.2, 16)
-    oracle.ball_query(x2[:, :256], x2, 0.3, 16)
-    oracle.ball_query(x4 + np.float32(0.05), xyz, 1.0, 1024)            # skip propagation, K=256
-    t['ball_query'] = time.time() - t0
-    t0 = time.time()
-    oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx1)
-    oracle.group_points(np.random.default_rng(0).normal(size=(1, 128, 2048)).astype(np.float32), idx2)
-    d2, i3nn = oracle.three_nn(x2, x3)
-    oracle.three_interpolate(np.zeros((1, 256, 512), np.float32), i3nn, d2)
-    t['group_interp'] = time.time() - t0
-    # decoder: sample of query points of one proposal, extrapolated by point count
-    from rfdnet_amd.iscnet.occ_decoder import DecoderCBatchNorm
-    dec = DecoderCBatchNorm(dim=3, z_dim=32, c_dim=512)
-    synthetic.load_seeded(dec, 1)
-    blob = oracle.decoder_param_blob({k: v.numpy() for k, v in dec.state_dict().items()})
-    rng = np.random.default_rng(0)
-    zc = np.zeros((1, 32), np.float32)
-    cc = rng.normal(size=(1, 512)).astype(np.float32)
+class StressBackend(HipBackend):
+    """configs[2]: the decoder alone on 256 proposals x 262 144 uniform query points in the padded unit
+    cube, codes ~ N(0,1).  A step = one decode of all 67.1 M points."""
 
-    def dec_time(n):
-        p = ((rng.random((1, n, 3)) - 0.5) * 1.1).astype(np.float32)
-        t0 = time.time()
-        oracle.decoder_cbn(blob, p, zc, cc)
-        return time.time() - t0
+    name = "stress"
+    K, T = 256, 262144
 
-    dec_time(8192)                                   # spin up the OpenMP team
-    t_cal = max(dec_time(32768), 1e-4)
-    n_s = int(min(4 << 20, max(65536, 32768 * 10.0 / t_cal)))   # ~10 s of CPU work
-    t_dec_s = dec_time(n_s)
-    t['decode_extrapolated'] = t_dec_s * n_queries_per_scene / n_s
-    # MISE: octree bookkeeping for a sample of proposals on an analytic field
-    t0 = time.time()
-    n_m = 4
-    for _ in range(n_m):
-        m = oracle.MISE(args.resolution0, args.upsampling_steps, 0.0)
-        q = m.query()
-        while q.shape[0]:
-            c = q.astype(np.float64) / m.resolution - 0.5
-            m.update(q, 0.35 - np.sqrt((c ** 2).sum(-1)))
-            q = m.query()
-        m.to_dense()
-    t['mise_extrapolated'] = (time.time() - t0) / n_m * n_prop
-    total = sum(t.values())
-    return {"value": 1.0 / total, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": ("oracle FPS/ball_query/group/three_nn on the full scene (%.1fs measured), "
-                       "decoder on %d of %d query points (%.1fs measured, extrapolated), MISE octree "
-                       "on %d of %d proposals; MLPs and marching cubes excluded (lower bound on CPU time)"
-                       % (t['fps'] + t['ball_query'] + t['group_interp'], n_s, n_queries_per_scene,
-                          t_dec_s, n_m, n_prop)),
-            "stage_s": {k: round(v, 3) for k, v in t.items()}}
+    def __init__(self, args, rank, local_rank, world):
+        import numpy as np
+        import torch
+        from rfdnet_amd import _lib, synthetic
+        from rfdnet_amd.iscnet import occ_decoder
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+        self.one_dev = os.environ.get("RFD_BENCH_ONE_DEVICE") == "1"
+        dev_index = 0 if self.one_dev else local_rank
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
+        self.dist_backend = "gloo" if self.one_dev else "nccl"
+        self.args, self.torch, self._lib = args, torch, _lib
+        self.S, self.NB, self.world, self.pool = 1, 1, world, world
+        dec = occ_decoder.DecoderCBatchNorm(dim=3, z_dim=32, c_dim=512, hidden_size=256)
+        synthetic.load_seeded(dec, 3)
+        dec = dec.to(self.device).eval()
+        dec.mode = occ_decoder.MODE_F16X3 if args.mode == "f16x3" else occ_decoder.MODE_F16X1
+        self.dec = dec
+        self.timers = [DecodeTimer(dec)]
+        self.streams = [torch.cuda.Stream(self.device)]
+        rng = np.random.default_rng(100 + rank)
+        K, T = self.K, self.T
+        self.pts = torch.from_numpy(((rng.random((K * T, 3)) - 0.5) * 1.1).astype(np.float32)).to(self.device)
+        c = torch.from_numpy(rng.normal(0, 1, (K, 512)).astype(np.float32)).to(self.device)
+        z = torch.zeros(K, 32, device=self.device)
+        with torch.no_grad():
+            self.table, self.fc_p_w = dec.fold(z, c)
+        self.tile_prop = torch.arange(K, dtype=torch.int32, device=self.device).repeat_interleave(T // 128)
+        torch.cuda.synchronize()
+
+    def worker_end(self, w, ctx):
+        self.streams[w].synchronize()
+        ctx.__exit__(None, None, None)
+
+    def run_pass(self, w, ids):
+        with self.torch.no_grad():
+            for _ in ids:
+                self.dec.decode_tiles(self.pts, self.tile_prop, self.table, self.fc_p_w)
+        return self.K * len(ids), 0, 0, self.K * self.T * len(ids)
+
+    def kernel_name(self):
+        return "%s<%d>" % ("occ_decode8_kernel" if self.dec.kernel == "w8" else "occ_decode_kernel",
+                           3 if self.args.mode == "f16x3" else 1)
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    # RFD_BENCH_ONE_DEVICE=1: dry run of the N>1 code path on a 1-GPU box (all ranks
-    # on cuda:0, gloo for the statistics exchange) -- never used for reported numbers
-    one_dev = os.environ.get("RFD_BENCH_ONE_DEVICE") == "1"
-    dev_index = 0 if one_dev else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+class StubBackend(object):
+    """RFD_BENCH_STUB=1: the launcher / sharding / statistics path with a CPU stand-in for the
+    scene (tests/test_bench_launcher.py; never a measurement).  Scene ids listed in
+    RFD_BENCH_STUB_FAIL raise, to exercise the per-scene failure accounting."""
+
+    name = "stub"
+    dist_backend = "gloo"
+
+    def __init__(self, args, rank, local_rank, world):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cpu")
+        self.args, self.S, self.NB, self.world = args, max(1, args.in_flight), max(1, args.batch), world
+        self.fail = {int(x) for x in os.environ.get("RFD_BENCH_STUB_FAIL", "").split(",") if x}
+        self.seen = []
+
+    def sync(self):
+        pass
+
+    def worker_begin(self, w):
+        return None
+
+    def worker_end(self, w, ctx):
+        pass
+
+    def run_pass(self, w, ids):
+        time.sleep(0.002)
+        self.seen += list(ids)
+        if self.fail & set(ids):
+            raise RuntimeError("stub scene %s failed" % sorted(self.fail & set(ids)))
+        return 256 * len(ids), 1000 * len(ids), 2000 * len(ids), sum(100 + i for i in ids)
+
+    def decode_totals(self):
+        return [1.0, 128, 1]
+
+    def set_timing(self, on):
+        pass
+
+    def final_check(self):
+        pass
+
+    def kernel_name(self):
+        return "stub"
+
+
+# ------------------------------------------------------------------------ job ---
+def run_job(args, be, rank, world, dist):
+    """warm-up, barrier, K timed steps, barrier -> per-rank statistics vector."""
+    from concurrent.futures import ThreadPoolExecutor
+    S, NB = be.S, be.NB
+    per_step = S * NB * world                              # scenes per step over the whole job
+
+    def shard(first_step, n_steps):
+        """this rank's scenes of steps [first_step, first_step + n_steps), split over its workers"""
+        lo, hi = first_step * per_step, (first_step + n_steps) * per_step
+        mine = [i for i in sharding.scene_ids_for_rank(hi, rank, world) if i >= lo]
+        return [sharding.scene_ids_for_worker(mine, w, S, NB) for w in range(S)]
+
+    def worker(w, passes):
+        tot, failed = [0, 0, 0, 0], 0
+        ctx = be.worker_begin(w)
+        try:
+            for ids in passes:
+                try:
+                    r = be.run_pass(w, ids)
+                    tot = [a + b for a, b in zip(tot, r)]
+                except Exception as e:                    # scene marked failed, the sweep goes on
+                    failed += len(ids)
+                    sys.stderr.write("[rank %d] scene(s) %s failed: %s: %s\n" % (rank, ids, type(e).__name__, e))
+        finally:
+            be.worker_end(w, ctx)
+        return tot, failed
+
+    pool = ThreadPoolExecutor(max_workers=S)
+    if args.warmup:
+        list(pool.map(lambda w: worker(w, shard(0, args.warmup)[w]), range(S)))
+    be.sync()
+    if dist is not None:
+        dist.barrier()
+    be.sync()
+    be.set_timing(True)
+    plan = shard(args.warmup, args.steps)
+    t0 = time.perf_counter()
+    res = list(pool.map(lambda w: worker(w, plan[w]), range(S)))
+    be.sync()
+    if dist is not None:
+        dist.barrier()
+    be.sync()
+    elapsed = time.perf_counter() - t0
+    dec_ms, dec_pts, dec_launches = be.decode_totals()
+    be.set_timing(False)
+    be.final_check()
+    n_meshes, nv, nt, nq = (sum(r[0][i] for r in res) for i in range(4))
+    failed = sum(r[1] for r in res)
+    n_scenes = sum(len(ids) for p in plan for ids in p)
+    single = None
+    if not args.no_latency and be.name == "hip" and rank == 0:
+        # one scene at a time on one stream: the latency reading of "a single scene per GPU"
+        L = 3
+        worker(0, [[0]])
+        be.sync()
+        t1 = time.perf_counter()
+        worker(0, [[i * world] for i in range(L)])
+        be.sync()
+        single = (time.perf_counter() - t1) / L
+    stats = sharding.pack_stats(steps=n_scenes - failed, elapsed_s=elapsed, n_meshes=n_meshes, n_vertices=nv,
+                                n_triangles=nt, n_queries=nq, decode_ms=dec_ms, decode_points=dec_pts,
+                                decode_launches=dec_launches, failed=failed)
+    return stats, single
+
+
+def traffic_per_query():
+    """HBM bytes per query point of the decoder from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this benchmark; counters cannot be read from
+    inside the process).  None when the file is absent."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            d = json.load(f)
+        return float(d["bytes_per_query"]), d.get("source", TRAFFIC_FILE)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+def main(argv=None):
+    args = parse(argv)
+    if args.gpus > 1 and not sharding.launched():
+        # `python bench.py --gpus N`: become the launcher of N ranks (one per GPU)
+        sys.exit(sharding.launch_local_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else argv,
+                                             args.gpus))
+    rank, local_rank, world = sharding.rank_env()
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node %d (or unset WORLD_SIZE "
+                 "and let bench.py spawn its own ranks)" % (args.gpus, world, args.gpus))
+    cls = StubBackend if os.environ.get("RFD_BENCH_STUB") == "1" else \
+        StressBackend if args.config == "stress" else HipBackend
+    be = cls(args, rank, local_rank, world)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo" if one_dev else "nccl")   # "nccl" = RCCL over xGMI
-    assert world == args.gpus or world == 1, (world, args.gpus)
-
-    from concurrent.futures import ThreadPoolExecutor
-    from rfdnet_amd import _lib, synthetic
-    S = max(1, args.in_flight)
-    # one model replica, stream, mesh sink and decoder timer per in-flight scene
-    nets = [build_net(args, device) for _ in range(S)]
-    timers = [DecodeTimer(n.completion.decoder) for n in nets]
-    streams = [torch.cuda.Stream(device) for _ in range(S)]
-    sinks = [MeshSink(device) for _ in range(S)]
-    # two scenes per worker, resident in HBM before timing
-    NB = max(1, args.batch)
-    scenes = [[torch.from_numpy(np.stack([synthetic.synthetic_scene(seed=10 + 100 * rank + 7 * w + s + 1000 * b,
-                                                                      n_points=args.points) for b in range(NB)]))
-               .to(device) for s in range(2)] for w in range(S)]
-    torch.cuda.synchronize()
-
-    def worker(w, n_steps, first):
-        torch.cuda.set_device(device)
-        tot = [0, 0, 0, 0]
-        with torch.cuda.stream(streams[w]):
-            for s in range(n_steps):
-                r = run_scene(nets[w], scenes[w][(first + s) % 2], sinks[w])
-                tot = [a + b for a, b in zip(tot, r)]
-            sinks[w].drain()
-            streams[w].synchronize()
-        return tot
-
-    pool = ThreadPoolExecutor(max_workers=S)
-    list(pool.map(lambda w: worker(w, args.warmup, 0), range(S)))
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    for tm in timers:
-        tm.enabled = True
-    base_evt = torch.cuda.Event(enable_timing=True)
-    base_evt.record()
-    t0 = time.perf_counter()
-    res = list(pool.map(lambda w: worker(w, args.steps, args.warmup), range(S)))
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    for tm in timers:
-        tm.enabled = False
-    _lib.device_status()
-    n_meshes, nv, nt, nq = (sum(r[i] for r in res) for i in range(4))
-    n_scenes = args.steps * S * NB
-
-    from rfdnet_amd import sharding
-    ivals = [iv for tm in timers for iv in tm.intervals(base_evt)]
-    # launches are serialised (DECODE_LOCK), so the sum of their durations == the union of their spans
-    dsum = {"total_ms": sum(e - b for b, e, _ in ivals), "points": sum(iv[2] for iv in ivals),
-            "launches": len(ivals), "union_ms": union_ms(ivals)}
-    stats = sharding.pack_stats(steps=n_scenes, elapsed_s=elapsed, n_meshes=n_meshes, n_vertices=nv,
-                                n_triangles=nt, n_queries=nq, decode_ms=dsum["total_ms"],
-                                decode_points=dsum["points"], decode_launches=dsum["launches"])
-    gathered = sharding.gather_stats(stats, device, dist)     # the path's only exchange step
+        dist.init_process_group(backend=be.dist_backend)
+    stats, single = run_job(args, be, rank, world, dist)
+    gathered = sharding.gather_stats(stats, be.device, dist)     # the path's only exchange step
     value_all, t_max = sharding.job_throughput(gathered)
-    scenes_total = float(gathered[:, 0].sum())
 
     if rank == 0:
-        value = value_all
-        dec_ms = float(gathered[:, 6].sum())
-        dec_pts = float(gathered[:, 5].sum())      # real query points (tile padding excluded)
-        dec_launches = float(gathered[:, 8].sum())
+        F = sharding.STAT_FIELDS.index
+        scenes_total = float(gathered[:, F("steps")].sum())
+        dec_ms = float(gathered[:, F("decode_ms")].sum())
+        dec_pts = float(gathered[:, F("n_queries")].sum())      # real query points (tile padding excluded)
+        dec_launches = float(gathered[:, F("decode_launches")].sum())
+        failed = int(gathered[:, F("failed")].sum())
         ach = dec_pts * FLOP_PER_QUERY / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else 0.0
+        bpq, bpq_src = traffic_per_query()
+        cfgd = dict(CONFIGS[args.config], points=args.points, resolution0=args.resolution0,
+                    upsampling_steps=args.upsampling_steps, res=args.resolution0 << args.upsampling_steps)
+        stress = args.config == "stress"
+        if stress:
+            metric, unit, value = "occupancy-decoder query points/sec (256 proposals x 262144 points)", "points/s", \
+                dec_pts / t_max
+        else:
+            metric, unit, value = "scenes/sec end-to-end reconstruction (ScanNet, %d^3 %s)" % (
+                cfgd["res"], "MISE" if args.upsampling_steps else "dense grid"), "scenes/s", value_all
+        per = max(scenes_total, 1.0)
         out = {
-            "metric": "scenes/sec end-to-end reconstruction (ScanNet, 64^3 MISE)",
-            "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (point ops, MLPs); f16x3 split MFMA with f32 accumulate (decoder, fp32-class)"
                      if args.mode == "f16x3" else "f32; f16 MFMA decoder (throughput mode, NOT parity)",
             "data": "synthetic (seeded ScanNet-like scenes, seeded random-init weights)",
-            "config": {"workload": "configs[1]: one ScanNet-like scene per forward pass, %d points, 256 proposals, "
-                                   "%d^3 MISE (res0=%d, steps=%d), meshes to host"
-                                   % (args.points, args.resolution0 << args.upsampling_steps,
-                                      args.resolution0, args.upsampling_steps),
-                       "proposals_per_scene": int(gathered[:, 2].sum() / scenes_total),
-                       "queries_per_scene": int(gathered[:, 5].sum() / scenes_total),
-                       "vertices_per_scene": int(gathered[:, 3].sum() / scenes_total),
-                       "scenes_in_flight_per_gpu": S * NB, "scenes_per_forward": NB,
-                       "scenes_per_step": S * NB * world,
-                       "parallelism": "scenes sharded across GPUs, dp%d; %d forward passes of %d scene(s) in flight per GPU"
-                                      % (world, S, NB)},
-            "roofline": {"bound": "mfma",
-                         "kernel": "%s<%d>" % ("occ_decode8_kernel" if nets[0].completion.decoder.kernel == "w8"
-                                               else "occ_decode_kernel", 3 if args.mode == "f16x3" else 1),
+            "config": {"workload": cfgd["name"] % cfgd,
+                       "proposals_per_scene": int(gathered[:, F("n_meshes")].sum() / per),
+                       "queries_per_scene": int(dec_pts / per),
+                       "vertices_per_scene": int(gathered[:, F("n_vertices")].sum() / per),
+                       "scenes_in_flight_per_gpu": be.S * be.NB, "scenes_per_forward": be.NB,
+                       "scenes_per_step": be.S * be.NB * world, "scenes_done": int(scenes_total),
+                       "scenes_failed": failed,
+                       "parallelism": "scenes sharded across GPUs (scene i -> rank i mod %d), dp%d; %d forward "
+                                      "passes of %d scene(s) in flight per GPU" % (world, world, be.S, be.NB)},
+            "roofline": {"bound": "mfma", "kernel": be.kernel_name(),
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_PEAK_TFLOPS,
-                         # HBM bytes per launch: the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
-                         # rocprofv3 --pmc runs of this benchmark, profiles/r01_t_decoder_bench_pmc.txt)
-                         # give 14.6 B per query point; scaled to this run's average launch
-                         "traffic": TRAFFIC_BYTES_PER_QUERY * dec_pts / dec_launches if dec_launches else None,
-                         "traffic_source": "14.6 B/query from rocprofv3 PMC passes on the decoder launches of this "
-                                           "benchmark (profiles/r01_t_decoder_bench_pmc.txt) x queries per launch",
+                         "traffic": bpq * dec_pts / dec_launches if (bpq and dec_launches) else None,
+                         "traffic_source": ("%.1f B per query point x queries per launch; NOT measured by this "
+                                            "process (PMC counters need rocprofv3): %s" % (bpq, bpq_src))
+                         if bpq else None,
                          "launches": int(dec_launches),
                          "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
                          "algorithmic_flop_per_launch": dec_pts * FLOP_PER_QUERY / dec_launches if dec_launches else None,
-                         "note": "algorithmic FLOPs (1 312 768 per query point); f16x3 issues 3x that on the MFMA pipe"},
+                         "note": "algorithmic FLOPs (1 312 768 per query point) over HIP-event time of the decoder "
+                                 "launches inside the timed region; f16x3 issues 3x that on the MFMA pipe"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, int(gathered[0, 5] / n_scenes), int(gathered[0, 2] / n_scenes))
+        if single is not None:
+            out["single_scene"] = {"scenes_in_flight": 1, "ms_per_scene": 1e3 * single,
+                                   "scenes_per_s": 1.0 / single}
+        if world == 1 and not args.no_cpu_baseline and be.name != "stub":
+            from oracle import cpu_baseline                       # the checker's CPU port, timed beside
+            if stress:
+                out["cpu_baseline"] = cpu_baseline.run_decoder_only()
+            else:
+                out["cpu_baseline"] = cpu_baseline.run(args.points, args.resolution0, args.upsampling_steps,
+                                                       int(dec_pts / per), int(gathered[0, F("n_meshes")] / per))
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,320 @@
+"""CPU baseline of the whole hot path (TEST / MEASUREMENT INFRASTRUCTURE, NOT PRODUCT CODE).
+
+Imported only by bench.py's `cpu_baseline` leg.  SURVEY.md §8(d): the reference has no CPU
+implementation of its point ops, so the baseline is a PORT --
+
+  * the C oracle (oracle/rfd_oracle.c, OpenMP) for FPS / ball query / grouping / three_nn /
+    three_interpolate, MISE and marching cubes,
+  * PyTorch-CPU fp32 for every MLP, with the module semantics of the reference restated as
+    plain torch layers (random weights: this is a timing, not a parity, leg):
+      shared MLPs of the SA / FP layers   pointnet2_modules.py:9-19, 244-255, 395-403
+      voting / proposal heads             vote_module.py:34-61, proposal_module.py:85-124
+      STN3d / STNkd / PointSeg            pointseg.py:7-166 (un-factored: 1088-channel head)
+      ResnetPointnet                      layers.py:340-392 (cat([net, pooled]) materialised)
+      DecoderCBatchNorm                   occ_decoder.py:110-123, layers.py:98-107, 226-242
+                                          (per proposal, <= 100 000 points per call as
+                                          generator.py:123-143 does)
+  on the host cores of the box, same scene, bounded samples extrapolated to one scene.
+Every stage is reported (`stage_s`), plus 1-core figures for FPS and ball query.
+"""
+import time
+
+import numpy as np
+
+
+def _mlp2d(torch, dims):
+    nn = torch.nn
+    layers = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        layers += [nn.Conv2d(a, b, 1, bias=False), nn.BatchNorm2d(b), nn.ReLU(inplace=True)]
+    return nn.Sequential(*layers).eval()
+
+
+def _mlp1d(torch, dims, last_plain=False):
+    nn = torch.nn
+    layers = []
+    n = len(dims) - 1
+    for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        layers.append(nn.Conv1d(a, b, 1))
+        if not (last_plain and i == n - 1):
+            layers += [nn.BatchNorm1d(b), nn.ReLU(inplace=True)]
+    return nn.Sequential(*layers).eval()
+
+
+class _TNet(object):
+    def __init__(self, torch, k_in, k_out):
+        nn = torch.nn
+        self.torch = torch
+        self.conv = _mlp1d(torch, [k_in, 64, 128, 1024])
+        self.fc = nn.Sequential(nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(),
+                                nn.Linear(512, 256), nn.BatchNorm1d(256), nn.ReLU(),
+                                nn.Linear(256, k_out * k_out)).eval()
+        self.k = k_out
+
+    def __call__(self, x):
+        g = self.conv(x).max(2)[0]
+        return (self.fc(g) + self.torch.eye(self.k).view(1, -1)).view(-1, self.k, self.k)
+
+
+class _PointSeg(object):
+    """pointseg.py:85-166 with feature_transform=True, global_feat=False"""
+
+    def __init__(self, torch, channel):
+        nn = torch.nn
+        self.torch = torch
+        self.stn = _TNet(torch, channel, 3)
+        self.conv1 = _mlp1d(torch, [channel, 64])
+        self.fstn = _TNet(torch, 64, 64)
+        self.conv2 = _mlp1d(torch, [64, 128])
+        self.conv3 = nn.Sequential(nn.Conv1d(128, 1024, 1), nn.BatchNorm1d(1024)).eval()
+        self.head = _mlp1d(torch, [1088, 512, 256, 128, 2], last_plain=True)
+
+    def __call__(self, x):                               # (B, D, N)
+        torch = self.torch
+        B, D, N = x.shape
+        trans = self.stn(x)
+        xt = x.transpose(2, 1)
+        xt = torch.cat([torch.bmm(xt[..., :3], trans), xt[..., 3:]], dim=2)
+        h = self.conv1(xt.transpose(2, 1))
+        tf = self.fstn(h)
+        h = torch.bmm(h.transpose(2, 1), tf).transpose(2, 1)
+        g = self.conv3(self.conv2(h)).max(2, keepdim=True)[0]
+        y = self.head(torch.cat([g.repeat(1, 1, N), h], 1))
+        return torch.log_softmax(y.transpose(2, 1).reshape(-1, 2), -1).view(B, N, 2)
+
+
+class _ResnetPointnet(object):
+    def __init__(self, torch, dim, hidden, c_dim):
+        nn = torch.nn
+        self.torch = torch
+        self.fc_pos = nn.Linear(dim, 2 * hidden)
+        self.blocks = [(nn.Linear(2 * hidden, hidden), nn.Linear(hidden, hidden),
+                        nn.Linear(2 * hidden, hidden, bias=False)) for _ in range(5)]
+        self.fc_c = nn.Linear(hidden, c_dim)
+
+    def _block(self, i, x):
+        torch = self.torch
+        fc0, fc1, sc = self.blocks[i]
+        ax = torch.relu(x)
+        return sc(ax) + fc1(torch.relu(fc0(ax)))
+
+    def __call__(self, p):                               # (B, T, dim)
+        torch = self.torch
+        net = self._block(0, self.fc_pos(p))
+        for i in range(1, 5):
+            pooled = net.max(1, keepdim=True)[0].expand(net.size())
+            net = self._block(i, torch.cat([net, pooled], 2))
+        return self.fc_c(torch.relu(net.max(1)[0]))
+
+
+class _Decoder(object):
+    """DecoderCBatchNorm as the module computes it (nothing folded)."""
+
+    def __init__(self, torch, c_dim=512, hidden=256, z_dim=32):
+        nn = torch.nn
+        self.torch = torch
+        self.fc_p = nn.Conv1d(3, hidden, 1)
+        self.fc_z = nn.Linear(z_dim, hidden)
+
+        def cbn():
+            return (nn.Conv1d(c_dim, hidden, 1), nn.Conv1d(c_dim, hidden, 1),
+                    nn.BatchNorm1d(hidden, affine=False).eval())
+        self.blocks = [(cbn(), nn.Conv1d(hidden, hidden, 1), cbn(), nn.Conv1d(hidden, hidden, 1))
+                       for _ in range(5)]
+        self.bn = cbn()
+        self.fc_out = nn.Conv1d(hidden, 1, 1)
+
+    @staticmethod
+    def _cbn(m, x, c):
+        g, b, bn = m
+        return g(c) * bn(x) + b(c)
+
+    def __call__(self, p, z, c):                          # p (1,T,3), z (1,32), c (1,512)
+        torch = self.torch
+        c = c.unsqueeze(2)
+        net = self.fc_p(p.transpose(1, 2)) + self.fc_z(z).unsqueeze(2)
+        for b0, fc0, b1, fc1 in self.blocks:
+            h = fc0(torch.relu(self._cbn(b0, net, c)))
+            net = net + fc1(torch.relu(self._cbn(b1, h, c)))
+        return self.fc_out(torch.relu(self._cbn(self.bn, net, c))).squeeze(1)
+
+
+def _timed(fn, reps=1):
+    fn()                                                   # warm (thread pools, allocator)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def run(points=80000, resolution0=32, upsampling_steps=1, n_queries_per_scene=None, n_prop=256,
+        budget_s=20.0):
+    """-> the `cpu_baseline` object of bench.py's JSON line."""
+    import torch
+    from oracle import oracle
+    from rfdnet_amd import synthetic
+    oracle.build()
+    cores = oracle.num_threads()
+    torch.set_num_threads(cores)
+    t, sample = {}, {}
+    pc = synthetic.synthetic_scene(seed=10, n_points=points, n_raw=120000 if points > 60000 else 30000)
+    xyz = np.ascontiguousarray(pc[None, :, :3])
+
+    # ---- point ops: C oracle, all cores (full scene) -------------------------------------
+    t0 = time.perf_counter()
+    i1 = oracle.furthest_point_sampling(xyz, 2048)
+    x1 = xyz[:, i1[0]]
+    i2 = oracle.furthest_point_sampling(x1, 1024); x2 = x1[:, i2[0]]
+    i3 = oracle.furthest_point_sampling(x2, 512); x3 = x2[:, i3[0]]
+    i4 = oracle.furthest_point_sampling(x3, 256); x4 = x3[:, i4[0]]
+    oracle.furthest_point_sampling(x2, 256)
+    t['fps'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    idx1 = oracle.ball_query(x1, xyz, 0.2, 64)
+    idx2 = oracle.ball_query(x2, x1, 0.4, 32)
+    oracle.ball_query(x3, x2, 0.8, 16)
+    oracle.ball_query(x4, x3, 1.2, 16)
+    oracle.ball_query(x2[:, :256], x2, 0.3, 16)
+    idx_sp = oracle.ball_query(x4 + np.float32(0.05), xyz, 1.0, 1024)          # skip propagation, K=256
+    t['ball_query'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx1)
+    oracle.group_points(np.random.default_rng(0).normal(size=(1, 128, 2048)).astype(np.float32), idx2)
+    oracle.group_points(np.ascontiguousarray(pc[None].transpose(0, 2, 1)), idx_sp)
+    d2, i3nn = oracle.three_nn(x2, x3)
+    oracle.three_interpolate(np.zeros((1, 256, 512), np.float32), i3nn, d2)
+    t['group_interp'] = time.perf_counter() - t0
+    # 1-core figures (reported, not part of the total): FPS rounds and ball-query centres scale linearly
+    one = {}
+    oracle.set_num_threads(1)
+    try:
+        t0 = time.perf_counter()
+        oracle.furthest_point_sampling(xyz, 129)
+        one['fps_sa1_s'] = (time.perf_counter() - t0) * 2047 / 128
+        t0 = time.perf_counter()
+        oracle.ball_query(x1[:, :128], xyz, 0.2, 64)
+        one['ball_query_sa1_s'] = (time.perf_counter() - t0) * 2048 / 128
+    finally:
+        oracle.set_num_threads(cores)
+
+    # ---- MLPs: PyTorch-CPU fp32, module semantics, all cores ------------------------------
+    with torch.no_grad():
+        sa = [(_mlp2d(torch, [4, 64, 64, 128]), torch.randn(1, 4, 2048, 64)),
+              (_mlp2d(torch, [131, 128, 128, 256]), torch.randn(1, 131, 1024, 32)),
+              (_mlp2d(torch, [259, 128, 128, 256]), torch.randn(1, 259, 512, 16)),
+              (_mlp2d(torch, [259, 128, 128, 256]), torch.randn(1, 259, 256, 16))]
+        fp = [(_mlp2d(torch, [512, 256, 256]), torch.randn(1, 512, 512, 1)),
+              (_mlp2d(torch, [512, 256, 256]), torch.randn(1, 512, 1024, 1))]
+
+        def backbone():
+            for m, x in sa:
+                torch.nn.functional.max_pool2d(m(x.clone()), kernel_size=[1, x.size(3)])
+            for m, x in fp:
+                m(x.clone())
+        t['mlp_backbone'] = _timed(backbone)
+        vote = _mlp1d(torch, [256, 256, 256, 259], last_plain=True)
+        agg = _mlp2d(torch, [259, 128, 128, 128])
+        head = _mlp1d(torch, [128, 128, 128, 69], last_plain=True)
+        xv, xa, xh = torch.randn(1, 256, 1024), torch.randn(1, 259, 256, 16), torch.randn(1, 128, 256)
+
+        def vote_prop():
+            vote(xv)
+            torch.nn.functional.max_pool2d(agg(xa.clone()), kernel_size=[1, 16])
+            head(xh)
+        t['mlp_vote_proposal'] = _timed(vote_prop)
+
+        # skip propagation nets on a sample of proposals
+        seg, enc = _PointSeg(torch, 4), _ResnetPointnet(torch, 4 + 128, 512, 512)
+        ks = 8
+        xs, xe = torch.randn(ks, 4, 1024), torch.randn(ks, 1024, 132)
+        ts = _timed(lambda: (seg(xs), enc(xe)))
+        if ts < 0.15 * budget_s / 4:                         # fast box: widen the sample
+            ks = int(min(n_prop, max(8, ks * (0.15 * budget_s / 2) / ts)))
+            xs, xe = torch.randn(ks, 4, 1024), torch.randn(ks, 1024, 132)
+            ts = _timed(lambda: (seg(xs), enc(xe)))
+        t['skip_propagation_nets'] = ts * n_prop / ks
+        sample['skip_propagation_nets'] = "%d of %d proposals" % (ks, n_prop)
+
+        # decoder on a sample of query points
+        dec = _Decoder(torch)
+        z, c = torch.zeros(1, 32), torch.randn(1, 512)
+
+        def dec_time(n):
+            p = (torch.rand(1, n, 3) - 0.5) * 1.1
+            t0 = time.perf_counter()
+            left = n
+            while left > 0:                                 # generator.py:129-141: <=100 000 points per call
+                m = min(left, 100000)
+                dec(p[:, :m], z, c)
+                left -= m
+            return time.perf_counter() - t0
+        dec_time(4096)
+        t_cal = max(dec_time(16384), 1e-4)
+        n_s = int(min(2 << 20, max(16384, 16384 * (0.4 * budget_s) / t_cal)))
+        t_dec = dec_time(n_s)
+    if n_queries_per_scene is None:
+        n_queries_per_scene = n_prop * (resolution0 + 1) ** 3
+    t['decoder'] = t_dec * n_queries_per_scene / n_s
+    sample['decoder'] = "%d of %d query points (%.1f s measured)" % (n_s, n_queries_per_scene, t_dec)
+
+    # ---- MISE octree + marching cubes: C oracle on a sample of proposals --------------------
+    n_m = 4
+    grids = []
+    t0 = time.perf_counter()
+    if upsampling_steps > 0:
+        for _ in range(n_m):
+            m = oracle.MISE(resolution0, upsampling_steps, 0.0)
+            q = m.query()
+            while q.shape[0]:
+                cc = q.astype(np.float64) / m.resolution - 0.5
+                m.update(q, 0.35 - np.sqrt((cc ** 2).sum(-1)))
+                q = m.query()
+            grids.append(m.to_dense())
+        t['mise_octree'] = (time.perf_counter() - t0) / n_m * n_prop
+        sample['mise_octree'] = "%d of %d proposals (analytic sphere field)" % (n_m, n_prop)
+    else:
+        n = resolution0
+        idx = np.stack(np.meshgrid(*[np.linspace(-0.5, 0.5, n)] * 3, indexing="ij"), -1)
+        grids = [0.35 - np.sqrt((idx ** 2).sum(-1))] * n_m
+        t['mise_octree'] = 0.0
+    t0 = time.perf_counter()
+    for g in grids:
+        oracle.extract_mesh(g, 0.0)
+    t['marching_cubes'] = (time.perf_counter() - t0) / n_m * n_prop
+    sample['marching_cubes'] = "%d of %d proposals (%d^3 sphere grids)" % (n_m, n_prop, grids[0].shape[0])
+
+    total = sum(t.values())
+    return {"value": 1.0 / total, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": ("one scene of the same workload on %d host cores: C oracle point ops on the full scene; "
+                       "PyTorch-CPU fp32 MLPs of the backbone / voting / proposal stages in full; "
+                       "skip-propagation nets on %s; decoder on %s; MISE octree on %s; marching cubes on %s "
+                       "-- each extrapolated linearly to the scene"
+                       % (cores, sample['skip_propagation_nets'], sample['decoder'],
+                          sample.get('mise_octree', 'n/a (dense grid)'), sample['marching_cubes'])),
+            "stage_s": {k: round(v, 4) for k, v in t.items()},
+            "one_core_s": {k: round(v, 3) for k, v in one.items()},
+            "scene_s": round(total, 3)}
+
+
+def run_decoder_only(n_total=256 * 262144, budget_s=15.0):
+    """configs[2] on the host: the restated DecoderCBatchNorm on a bounded sample of the query
+    points, points/s."""
+    import torch
+    from oracle import oracle
+    cores = oracle.num_threads()
+    torch.set_num_threads(cores)
+    dec = _Decoder(torch)
+    z, c = torch.zeros(1, 32), torch.randn(1, 512)
+    with torch.no_grad():
+        def dec_time(n):
+            p = (torch.rand(1, n, 3) - 0.5) * 1.1
+            t0 = time.perf_counter()
+            dec(p, z, c)
+            return time.perf_counter() - t0
+        dec_time(4096)
+        t_cal = max(dec_time(16384), 1e-4)
+        n_s = int(min(100000, max(16384, 16384 * budget_s / t_cal)))
+        t = dec_time(n_s)
+    return {"value": n_s / t, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": "PyTorch-CPU fp32 DecoderCBatchNorm (module semantics) on %d of %d query points of one "
+                      "proposal (%.1f s measured)" % (n_s, n_total, t)}

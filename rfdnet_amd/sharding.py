@@ -6,10 +6,72 @@ data-path collective.  One process per GPU (`torch.distributed`, backend
 a fixed-length float64 statistics vector per rank at the end (latency-bound:
 <= 128 B per rank) plus the barrier that brackets the timed region.
 """
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 
 STAT_FIELDS = ("steps", "elapsed_s", "n_meshes", "n_vertices", "n_triangles", "n_queries",
-               "decode_ms", "decode_points", "decode_launches")
+               "decode_ms", "decode_points", "decode_launches", "failed")
+
+
+def rank_env():
+    """(rank, local_rank, world) of this process as torch.distributed.run exports them."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def launched():
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_local_ranks(script, argv, nproc, env=None, timeout=None):
+    """One process per GPU of THIS node: re-executes `script argv` nproc times with the
+    environment torch.distributed.run would set (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT), rank 0 inheriting stdout.  Returns the worst exit
+    code; if a rank fails the others are terminated (no orphan holding a GPU)."""
+    base = dict(os.environ)
+    base.update(env or {})
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(nproc),
+                LOCAL_WORLD_SIZE=str(nproc))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes)
+    procs = []
+    for r in range(nproc):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    import time
+    t_end = None if timeout is None else time.time() + timeout
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            c = p.poll()
+            if c is not None:
+                alive.remove(p)
+                if c != 0:
+                    rc = rc or c
+        if rc or (t_end is not None and time.time() > t_end):
+            for p in alive:
+                p.terminate()
+            for p in alive:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rc or 124
+        time.sleep(0.05)
+    return rc
 
 
 def scene_ids_for_rank(n_scenes, rank, world_size):
@@ -17,6 +79,13 @@ def scene_ids_for_rank(n_scenes, rank, world_size):
     if not (0 <= rank < world_size):
         raise ValueError("rank %d outside world of %d" % (rank, world_size))
     return list(range(rank, n_scenes, world_size))
+
+
+def scene_ids_for_worker(rank_ids, worker, n_workers, per_pass=1):
+    """Split a rank's scenes over its in-flight workers in passes of `per_pass` scenes:
+    pass j (scenes [j*per_pass, (j+1)*per_pass)) -> worker j mod n_workers."""
+    passes = [rank_ids[i:i + per_pass] for i in range(0, len(rank_ids), per_pass)]
+    return passes[worker::n_workers]
 
 
 def pack_stats(**kw):

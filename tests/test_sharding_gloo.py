@@ -28,7 +28,7 @@ def _worker(rank, world, port, n_scenes, q):
     dist.barrier()
     stats = sharding.pack_stats(steps=len(ids), elapsed_s=1.0 + rank, n_meshes=256 * len(ids),
                                 n_vertices=100 * rank, n_triangles=7, n_queries=sum(ids),
-                                decode_ms=5.0, decode_points=11, decode_launches=3)
+                                decode_ms=5.0, decode_points=11, decode_launches=3, failed=rank)
     g = sharding.gather_stats(stats, torch.device("cpu"), dist)
     q.put((rank, ids, g))
     dist.barrier()
@@ -61,9 +61,9 @@ def test_two_rank_sharding_and_stats_allgather(n_scenes):
 def test_single_process_needs_no_collective():
     g = sharding.gather_stats(sharding.pack_stats(steps=3, elapsed_s=0.5, n_meshes=1, n_vertices=2,
                                                   n_triangles=3, n_queries=4, decode_ms=5,
-                                                  decode_points=6, decode_launches=7),
+                                                  decode_points=6, decode_launches=7, failed=0),
                               torch.device("cpu"), None)
-    assert g.shape == (1, 9) and sharding.job_throughput(g) == (6.0, 0.5)
+    assert g.shape == (1, 10) and sharding.job_throughput(g) == (6.0, 0.5)
     assert sharding.scene_ids_for_rank(10, 3, 4) == [3, 7]
     with pytest.raises(ValueError):
         sharding.scene_ids_for_rank(4, 4, 4)
