@@ -199,9 +199,8 @@ def make_net():
             out['bb_' + k] = ep[k].numpy().astype(np.int32)
         for k in ('sa1_xyz', 'sa2_xyz', 'sa3_xyz', 'sa4_xyz'):
             out['bb_' + k] = ep[k].numpy()
-        for k, st in (('sa1_features', 37), ('sa2_features', 37), ('sa3_features', 17),
-                      ('sa4_features', 7), ('fp2_features', 37)):
-            out['bb_' + k] = sub(ep[k].numpy(), st)
+        for k in ('sa1_features', 'sa2_features', 'sa3_features', 'sa4_features', 'fp2_features'):
+            out['bb_' + k] = ep[k].numpy()                   # FULL tensors (round 2: no strided subsets)
         vote = vm.VotingModule(cfg)
         names, shp = shapes_arrays(synthetic.load_seeded(vote, 102))
         out['vote_names'], out['vote_shapes'] = names, shp
@@ -209,7 +208,7 @@ def make_net():
         vxyz, vfeat = vote(ep['fp2_xyz'], ep['fp2_features'])
         vfeat = vfeat.div(torch.norm(vfeat, p=2, dim=1).unsqueeze(1))      # demo.py:215-216
         out['vote_xyz'] = vxyz.numpy()
-        out['vote_features'] = sub(vfeat.numpy(), 37)
+        out['vote_features'] = vfeat.numpy()
         prop = pm.ProposalModule(cfg)
         names, shp = shapes_arrays(synthetic.load_seeded(prop, 103))
         out['prop_names'], out['prop_shapes'] = names, shp
@@ -222,7 +221,7 @@ def make_net():
                   'heading_residuals_normalized', 'size_scores', 'size_residuals_normalized',
                   'sem_cls_scores'):
             out['prop_' + k] = ep[k].numpy()
-        out['prop_features'] = sub(pf.numpy(), 7)
+        out['prop_features'] = pf.numpy()
         # skip propagation on 6 of the proposals
         skip = sp.SkipPropagation(cfg)
         names, shp = shapes_arrays(synthetic.load_seeded(skip, 104))

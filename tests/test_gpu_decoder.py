@@ -112,3 +112,41 @@ def test_eight_wave_kernel_gives_the_same_logits(hip, golden_dir, oracle):
     with torch.no_grad():
         out = d8(torch.from_numpy(pp).cuda(), torch.from_numpy(zz).cuda(), torch.from_numpy(cc).cuda())
     assert np.abs(out.cpu().numpy() - ref).max() < LOGIT_TOL
+
+
+def test_decoder_stress_config_full_size(hip, oracle):
+    """BASELINE configs[2] at full size: 256 proposals x 262 144 uniform query points (67.1 M), codes ~ N(0,1).
+    Size-independent checks: (i) a point's logit does not depend on where it sits -- permuting the
+    points of every proposal permutes the logits bit for bit; (ii) 1000 sampled points against the
+    CPU oracle decoder (module semantics, occ_decoder.py:110-123) within 1e-4; (iii) no device
+    status bit (f16 range) is raised."""
+    K, T = 256, 262144
+    dec = seeded_decoder(3)
+    sd = OrderedDict((k, v.detach().cpu().numpy()) for k, v in dec.state_dict().items())
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    p = (torch.rand(K, T, 3, device="cuda", generator=g) - 0.5) * 1.1
+    c = torch.randn(K, 512, device="cuda", generator=g)
+    z = torch.zeros(K, 32, device="cuda")
+    with torch.no_grad():
+        out = dec(p, z, c)
+        hip.device_status()
+        assert out.shape == (K, T) and torch.isfinite(out).all()
+        perm = torch.randperm(T, device="cuda", generator=g)
+        out_p = dec(p[:, perm].contiguous(), z, c)
+        hip.device_status()
+    assert torch.equal(out[:, perm], out_p)
+    rng = np.random.default_rng(11)
+    kk = rng.integers(0, K, 1000)
+    tt = rng.integers(0, T, 1000)
+    order = np.argsort(kk, kind="stable")
+    kk, tt = kk[order], tt[order]
+    blob = oracle.decoder_param_blob(sd)
+    worst = 0.0
+    p_h, c_h, o_h = p[kk, tt].cpu().numpy(), c.cpu().numpy(), out[kk, tt].cpu().numpy()
+    for k in np.unique(kk):
+        m = kk == k
+        ref = oracle.decoder_cbn(blob, p_h[m][None], np.zeros((1, 32), np.float32), c_h[k][None])
+        worst = max(worst, float(np.abs(ref[0] - o_h[m]).max()))
+    print("stress config: max |dlogit| on the 1000-point oracle sample = %.2e" % worst)
+    assert worst < LOGIT_TOL

@@ -1,6 +1,10 @@
-"""GPU (-m gpu): the headline configuration at FULL size (BASELINE.json configs[1]: one scene of
-80 000 points, 256 proposals, MISE 32 -> 64) checked through size-independent properties --
-the small-case parity tests cannot run the oracle on 12 M query points.
+"""GPU (-m gpu): every single-GPU configuration of BASELINE.json at FULL size, checked through
+size-independent properties -- the small-case parity tests cannot run the oracle on 10^7 query
+points:
+  headline  configs[1]: 80 000 points, 256 proposals, MISE 32 -> 64
+  mise128   configs[4] per GPU: 80 000 points, 256 proposals, MISE 32 -> 128 (upsampling_steps 2)
+  dense32   configs[0]: 40 000 points sampled WITH replacement (duplicates), 256 proposals, dense 32^3
+(configs[2], the decoder stress, is in tests/test_gpu_decoder.py; configs[3] needs 8 GPUs.)
 
   * batch independence: the value grid of a proposal does not depend on which other proposals
     share the launches (MISE is data dependent per proposal, the decoder per point).  The
@@ -29,15 +33,25 @@ LOGIT_TOL = 1e-4
 PICK = (0, 97, 255)
 
 
-@pytest.fixture(scope="module")
-def scene(hip):
-    cfg = Config({'data': {'num_point': 80000}, 'generation': {'resolution_0': 32, 'upsampling_steps': 1}})
+CASES = {"headline": (80000, 120000, 32, 1), "mise128": (80000, 120000, 32, 2), "dense32": (40000, 30000, 32, 0)}
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def scene(request, hip, oracle):
+    n_points, n_raw, res0, steps = CASES[request.param]
+    cfg = Config({'data': {'num_point': n_points}, 'generation': {'resolution_0': res0, 'upsampling_steps': steps}})
     net = ISCNet(cfg)
     synthetic.load_seeded(net, 10)
     net = net.cuda().eval()
-    pc = torch.from_numpy(synthetic.synthetic_scene(seed=10, n_points=80000)[None]).cuda()
+    pc_np = synthetic.synthetic_scene(seed=10, n_points=n_points, n_raw=n_raw)
+    pc = torch.from_numpy(pc_np[None]).cuda()
     with torch.no_grad():
         end_points, feats = net.detect(pc)
+        if request.param == "dense32":
+            # the with-replacement scan holds exact duplicates: the FPS tie order matters here
+            assert np.unique(pc_np[:, :3], axis=0).shape[0] < n_points
+            ref = oracle.furthest_point_sampling(np.ascontiguousarray(pc_np[None, :, :3]), 2048)
+            assert np.array_equal(end_points['sa1_inds'].cpu().numpy(), ref)
         ids = net.select_proposals(end_points, 'all', pc)
         codes = net.object_codes(end_points, feats, ids, pc)
         cls = net.cls_codes(end_points, ids)
@@ -50,10 +64,17 @@ def scene(hip):
 
 def test_shapes_and_query_count(scene):
     net, gen, codes, cls, grids, stats = scene
-    assert codes.shape[0] == 256 and grids.shape == (256, 65, 65, 65)
+    res0, steps = gen.resolution0, gen.upsampling_steps
+    if steps == 0:
+        assert codes.shape[0] == 256 and grids.shape == (256, res0, res0, res0)
+        assert stats['n_queries'] == 256 * res0 ** 3
+    else:
+        R1 = (res0 << steps) + 1
+        assert codes.shape[0] == 256 and grids.shape == (256, R1, R1, R1)
+        assert stats['n_queries'] >= 256 * (res0 + 1) ** 3 and stats['rounds'] >= 2
+        assert stats['n_queries'] <= 256 * R1 ** 3
     assert torch.isfinite(grids).all()
-    assert stats['n_queries'] >= 256 * 33 ** 3 and stats['rounds'] >= 2
-    assert stats['n_queries'] <= 256 * 65 ** 3
+    print("%d^3: %d query points, %d rounds" % (grids.shape[1], stats['n_queries'], stats['rounds']))
 
 
 def test_batch_independence(scene):
@@ -63,32 +84,51 @@ def test_batch_independence(scene):
         alone = gen.generate_grids(codes[idx], cls[idx])
     together = grids[idx]
     diff = (alone - together).abs()
-    print("max |difference| between the 3-proposal and the 256-proposal run: %.3g" % diff.max().item())
-    assert diff.max().item() < 1e-5
+    n_bad = int((diff > 1e-5).sum().item())
+    print("3-proposal vs 256-proposal run: max |difference| %.3g, %d of %d grid points differ by > 1e-5"
+          % (diff.max().item(), n_bad, diff.numel()))
+    # MISE is data dependent: the two runs' logits differ by ~1e-7 (see above), and a logit that close
+    # to the threshold decides whether a voxel is split, i.e. whether up to 19 fine points are EVALUATED
+    # or FILLED from a neighbour (mise.pyx:142-163).  With 5 rounds at 128^3 this happens to a handful of
+    # voxels; everything else must agree, and no inside / outside decision away from the threshold may change
+    assert n_bad <= 64, n_bad
+    if gen.upsampling_steps <= 1:
+        assert diff.max().item() < 1e-5
     thr = gen.logit_threshold()
-    far = (together - thr).abs() > 1e-5
+    far = ((together - thr).abs() > 1e-5) & (diff <= 1e-5)
     assert torch.equal((alone >= thr)[far], (together >= thr)[far])
 
 
 def test_level0_lattice_carries_the_decoder_value(scene, oracle):
     net, gen, codes, cls, grids, stats = scene
     idx = torch.tensor(PICK, device=codes.device)
-    dense = copy.copy(gen)                       # same model, dense 33^3 evaluation (generator.py:91-97)
-    dense.resolution0, dense.upsampling_steps = 33, 0
-    with torch.no_grad():
-        direct = dense.generate_grids(codes[idx], cls[idx])               # (3,33,33,33)
-    lattice = grids[idx][:, ::2, ::2, ::2]
-    # the two paths build the coordinates differently (i/64 - 0.5 vs linspace): last-ulp inputs
-    assert (lattice - direct).abs().max().item() < LOGIT_TOL
+    res0, steps = gen.resolution0, gen.upsampling_steps
+    nl = res0 + 1 if steps else res0             # points per axis of the lattice that is always evaluated
+    if steps:
+        dense = copy.copy(gen)                   # same model, dense evaluation (generator.py:91-97)
+        dense.resolution0, dense.upsampling_steps = nl, 0
+        dense.__dict__.pop('_round0_cache', None)
+        with torch.no_grad():
+            direct = dense.generate_grids(codes[idx], cls[idx])           # (3,nl,nl,nl)
+        st = 1 << steps
+        lattice = grids[idx][:, ::st, ::st, ::st]
+        # the two paths build the coordinates differently (i/R - 0.5 vs linspace): last-ulp inputs
+        assert (lattice - direct).abs().max().item() < LOGIT_TOL
+    else:
+        lattice = grids[idx]
     # ... and a sample of them against the CPU oracle (models/iscnet/modules/occ_decoder.py:110-123)
     model = net.completion
     dec = model.decoder
     sd = OrderedDict((k, v.detach().cpu().numpy()) for k, v in dec.state_dict().items())
     blob = oracle.decoder_param_blob(sd)
     rng = np.random.default_rng(3)
-    ijk = rng.integers(0, 33, (len(PICK), 200, 3))
+    ijk = rng.integers(0, nl, (len(PICK), 200, 3))
     box = 1 + gen.padding
-    p = (box * (ijk.astype(np.float32) / np.float32(32) - np.float32(0.5))).astype(np.float32)
+    if steps:                                     # generator.py:106-109
+        p = (box * (ijk.astype(np.float32) / np.float32(nl - 1) - np.float32(0.5))).astype(np.float32)
+    else:                                         # generator.py:91-97: make_3d_grid (inclusive linspace)
+        g = oracle.make_3d_grid(-0.5, 0.5, nl, box).reshape(nl, nl, nl, 3)
+        p = g[ijk[..., 0], ijk[..., 1], ijk[..., 2]]
     c_in = codes[idx]
     if getattr(model, 'use_cls_for_completion', False):
         c_in = torch.cat([c_in, cls[idx]], dim=-1)

@@ -14,13 +14,21 @@ from rfdnet_amd.iscnet.config import Config
 pytestmark = pytest.mark.gpu
 
 
-def close_frac(a, b, rtol=2e-3, atol=2e-4):
-    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
-    return float((np.abs(a - b) <= atol + rtol * np.abs(b)).mean())
+REPORT = []
 
 
-def sub(t, step):
-    return t.detach().cpu().numpy().reshape(-1)[::step]
+def outliers(name, got, ref, rtol=1e-4, atol_rel=1e-5):
+    """FULL-tensor comparison at an fp32-class bound: |d| <= atol_rel * max|ref| + rtol * |ref|.
+    Returns the number of elements outside it; logs max abs error, the tensor's scale and that count."""
+    a = np.asarray(got.detach().cpu().numpy() if hasattr(got, "detach") else got, dtype=np.float64)
+    b = np.asarray(ref, dtype=np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = float(np.abs(b).max())
+    d = np.abs(a - b)
+    n_out = int((d > atol_rel * scale + rtol * np.abs(b)).sum())
+    REPORT.append("%-34s n=%8d  max|d| %.3e  scale %.3e  outside fp32-class bound: %d" % (name, b.size, d.max(), scale, n_out))
+    print(REPORT[-1])
+    return n_out
 
 
 @pytest.fixture(scope="module")
@@ -44,27 +52,43 @@ def test_backbone_vote_proposal_skip_match_reference(state):
             np.testing.assert_array_equal(ep[k].cpu().numpy(), fx['bb_' + k])
         for k in ('sa1_xyz', 'sa2_xyz', 'sa3_xyz', 'sa4_xyz'):
             np.testing.assert_array_equal(ep[k].cpu().numpy(), fx['bb_' + k])
-        for k, st in (('sa1_features', 37), ('sa2_features', 37), ('sa3_features', 17),
-                      ('sa4_features', 7), ('fp2_features', 37)):
-            assert close_frac(sub(ep[k], st), fx['bb_' + k]) > 0.999, k
+        # the backbone's sampling / grouping depends on the INPUT coordinates only, so nothing can
+        # flip: every element of every feature tensor must be at fp32 accuracy (summation order of
+        # the 1x1 convolutions is the only difference to the reference's CPU run)
+        for k in ('sa1_features', 'sa2_features', 'sa3_features', 'sa4_features', 'fp2_features'):
+            assert outliers('bb_' + k, ep[k], fx['bb_' + k]) == 0, k
 
         vote = VotingModule(cfg); synthetic.load_seeded(vote, 102); vote = vote.cuda().eval()
         vxyz, vfeat = vote(ep['fp2_xyz'], ep['fp2_features'])
         vfeat = vfeat.div(torch.norm(vfeat, p=2, dim=1).unsqueeze(1))
-        assert close_frac(vxyz.cpu().numpy(), fx['vote_xyz']) > 0.999
-        assert close_frac(sub(vfeat, 37), fx['vote_features']) > 0.999
+        assert outliers('vote_xyz', vxyz, fx['vote_xyz']) == 0
+        assert outliers('vote_features', vfeat, fx['vote_features']) == 0
 
         prop = ProposalModule(cfg); synthetic.load_seeded(prop, 103); prop = prop.cuda().eval()
         ep['seed_xyz'] = ep['fp2_xyz']
         ep, pf = prop(vxyz, vfeat, ep, True)
         np.testing.assert_array_equal(ep['aggregated_vote_inds'].cpu().numpy(),
                                       fx['prop_aggregated_vote_inds'])
+        # vote aggregation groups the VOTE coordinates (an MLP output, equal to ~1e-7 only): a vote
+        # within an ulp of a ball boundary may enter / leave one neighbourhood, which changes that
+        # proposal's row.  Rows are therefore compared one by one: a row is either at fp32 accuracy
+        # or counted as flipped; at most 1 % of the 256 proposals may flip.
+        n_rows_out = 0
         for k in ('aggregated_vote_xyz', 'center', 'objectness_scores', 'heading_scores',
                   'heading_residuals_normalized', 'size_scores', 'size_residuals_normalized',
                   'sem_cls_scores'):
-            # a vote within 1 ulp of a ball boundary may change one neighbourhood
-            assert close_frac(ep[k].cpu().numpy(), fx['prop_' + k]) > 0.99, k
-        assert close_frac(sub(pf, 7), fx['prop_features']) > 0.99
+            outliers('prop_' + k, ep[k], fx['prop_' + k])
+        got = torch.cat([ep[k].reshape(1, 256, -1) for k in ('center', 'objectness_scores', 'heading_scores',
+                         'heading_residuals_normalized', 'size_scores', 'size_residuals_normalized',
+                         'sem_cls_scores')] + [pf.transpose(1, 2)], dim=2)[0].cpu().numpy().astype(np.float64)
+        ref = np.concatenate([fx['prop_' + k].reshape(1, 256, -1) for k in ('center', 'objectness_scores',
+                              'heading_scores', 'heading_residuals_normalized', 'size_scores',
+                              'size_residuals_normalized', 'sem_cls_scores')]
+                             + [fx['prop_features'].transpose(0, 2, 1)], axis=2)[0].astype(np.float64)
+        row_bad = (np.abs(got - ref) > 1e-5 * np.abs(ref).max() + 1e-4 * np.abs(ref)).any(axis=1)
+        n_rows_out = int(row_bad.sum())
+        print("proposal rows not at fp32 accuracy (neighbourhood flips): %d of 256 %s" % (n_rows_out, np.where(row_bad)[0]))
+        assert n_rows_out <= 2
 
         skip = SkipPropagation(cfg); synthetic.load_seeded(skip, 104); skip = skip.cuda().eval()
         ids = torch.from_numpy(fx['skip_ids']).cuda()
@@ -73,7 +97,14 @@ def test_backbone_vote_proposal_skip_match_reference(state):
         ang = torch.from_numpy(fx['skip_angles']).cuda()
         codes = skip.generate(centers, ang, feats, pc)
         assert codes.shape == (1, 512, 6)
-        assert close_frac(codes.cpu().numpy(), fx['skip_codes'], rtol=5e-3, atol=5e-4) > 0.98
+        # six proposals; the object code is a max-pool over 1024 masked points after two argmax /
+        # ball-query decisions (PointSeg mask, r = 1 m grouping): compared per proposal, fp32-class
+        # or reported as a flipped decision
+        n_out = outliers('skip_codes', codes, fx['skip_codes'], rtol=2e-4, atol_rel=2e-5)
+        d = np.abs(codes.cpu().numpy().astype(np.float64) - fx['skip_codes'])[0]          # (512, 6)
+        per_prop = d.max(axis=0)
+        print("skip-propagation codes: max |d| per proposal", per_prop)
+        assert n_out == 0 or (per_prop > 2e-5 * np.abs(fx['skip_codes']).max()).sum() <= 1
 
 
 def test_sa_module_fused_path_equals_operator_composition(hip):
