@@ -55,6 +55,35 @@ def lib():
     return _lib
 
 
+class variant(object):
+    """`with oracle.variant(1): ...` -- run the point ops with another a*a+b*b+c*c evaluation
+    order (rfd_oracle.c ORACLE_SUMSQ_VARIANT: 1 = right-nested fma, 2 = no contraction).  Used only
+    to measure how much depends on the nvcc fma-order assumption."""
+
+    def __init__(self, v):
+        self.v = int(v)
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self.saved = _lib
+        if self.v:
+            path = os.path.join(_HERE, "liboracle_v%d.so" % self.v)
+            src = os.path.join(_HERE, "rfd_oracle.c")
+            if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(path)],
+                                      stdout=subprocess.DEVNULL)
+            l = C.CDLL(path)
+            assert l.oracle_sumsq_variant() == self.v
+            l.oracle_ball_query.argtypes = self.saved.oracle_ball_query.argtypes
+            _lib = l
+        return self
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.saved
+
+
 def _f(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(_f32p)

@@ -45,13 +45,30 @@
 
 /* ---- shared arithmetic helpers ------------------------------------------ */
 
-/* nvcc -fmad=true evaluation order of a*a + b*b + c*c (see header). */
+/* nvcc -fmad=true evaluation order of a*a + b*b + c*c (see header).
+ * ORACLE_SUMSQ_VARIANT builds the two other orders a compiler could plausibly pick, ONLY to
+ * measure how much of the output depends on the assumption (tools/fma_order_report.py,
+ * tests/test_fma_order.py); the shipped oracle and the HIP kernels use variant 0. */
+#ifndef ORACLE_SUMSQ_VARIANT
+#define ORACLE_SUMSQ_VARIANT 0
+#endif
 static inline float sumsq3(float a, float b, float c) {
+#if ORACLE_SUMSQ_VARIANT == 0
   float t = b * b;
   t = fmaf(a, a, t);
   t = fmaf(c, c, t);
   return t;
+#elif ORACLE_SUMSQ_VARIANT == 1 /* right-nested: fma(a,a, fma(b,b, c*c)) */
+  float t = c * c;
+  t = fmaf(b, b, t);
+  t = fmaf(a, a, t);
+  return t;
+#else /* no contraction at all (-fmad=false): (a*a + b*b) + c*c */
+  const float aa = a * a, bb = b * b, cc = c * c;
+  return (aa + bb) + cc;
+#endif
 }
+ORACLE_API int oracle_sumsq_variant(void) { return ORACLE_SUMSQ_VARIANT; }
 
 /* cuda_utils.h:13-19 opt_n_threads */
 ORACLE_API int oracle_opt_n_threads(int work_size) {
