@@ -18,6 +18,25 @@
 #include "common.h"
 #include "../../include/rfd_occ.h"
 
+#ifndef DEC8_DMA_ALT
+#define DEC8_DMA_ALT 0
+#endif
+#ifndef DEC8_DMA_SPREAD
+#define DEC8_DMA_SPREAD 0
+#endif
+#ifndef DEC8_SWAP
+#define DEC8_SWAP 0
+#endif
+#ifndef DEC8_PRIO
+#define DEC8_PRIO 0
+#endif
+#ifndef DEC8_NOREAD      // timing only: fragments are not re-read from LDS inside phases A / B
+#define DEC8_NOREAD 0
+#endif
+#ifndef DEC8_NODMA       // timing only: no LDS-DMA transfers after the priming
+#define DEC8_NODMA 0
+#endif
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -148,6 +167,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g4 = 4 * (lane >> 4), n = lane & 15;
   unsigned amax16 = 0u;
+#if DEC8_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration otherwise
+#endif
 
   const int t_begin = blockIdx.x * tiles_per_wg;
   const int t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
@@ -234,22 +256,48 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
         act_kstep<X3>(acc_cur[0], acc_cur[1], S1, T1, 32 * mb + g4, bhi, blo, amax16);
         // ---- phase A: fc_0 block mb+1 (two accumulator chains) with this iteration's LDS-DMA
         // pieces in between
+        auto issue_dma = [&](int j) {          // piece j (0..7) of this slab's two halves
+#if DEC8_NODMA
+          (void)j;
+#elif DEC8_DMA_ALT
+          // only one wave of each SIMD pair issues in a slab (alternating): 16 pieces = frags
+          // 8 (wave & 3) + 0..7 of both halves
+          if ((wave >> 2) == (c & 1)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int jj = 2 * j + u;          // 0..15
+              const int h = 2 * c + 3 + (jj >> 3);
+              if (h < N_HALVES || has_next) {
+                const int frag = (wave & 3) * 8 + (jj & 7);
+                const int hs = h >= N_HALVES ? h - N_HALVES : h;
+                __builtin_amdgcn_global_load_lds((gbl_void *)(packed + ((size_t)hs * HALF_FRAGS + frag) * 64 + lane),
+                                                 (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, 0);
+              }
+            }
+          }
+#else
+          const int h = 2 * c + 3 + (j >> 2);
+          if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, j & 3, wave, lane);
+#endif
+        };
+        auto phase_a = [&]() {
         if (mb < 7) {
           const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 2) & 3) * HALF_BYTES) + lane;
           half8 n0h = w[0], n0l = w[64], n1h = w[128], n1l = w[192];
 #pragma unroll
           for (int ks = 0; ks < 8; ++ks) {
             const half8 w0h = n0h, w0l = n0l, w1h = n1h, w1l = n1l;
-            if (ks < 7) {
+            if (ks < 7 && !DEC8_NOREAD) {
               n0h = w[(4 * ks + 4) * 64];
               n0l = w[(4 * ks + 5) * 64];
               n1h = w[(4 * ks + 6) * 64];
               n1l = w[(4 * ks + 7) * 64];
             }
-            {
-              const int h = 2 * c + 3 + (ks >> 2);
-              if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, ks & 3, wave, lane);
-            }
+#if DEC8_DMA_SPREAD
+            if (!(ks & 1)) issue_dma(ks >> 1);
+#else
+            issue_dma(ks);
+#endif
             acc_next[0] = mfma16(w0h, ahi[ks], acc_next[0]);
             acc_next[1] = mfma16(w1h, ahi[ks], acc_next[1]);
             if (X3) {
@@ -261,24 +309,25 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int h = 2 * c + 3 + (j >> 2);
-            if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, j & 3, wave, lane);
-          }
+          for (int j = 0; j < (DEC8_DMA_SPREAD ? 4 : 8); ++j) issue_dma(j);
         }
+        };
         // ---- phase B: H'[t] += fc_1[16t.., slab mb] a2', sixteen accumulators, two chains at a time
-        {
+        auto phase_b = [&]() {
           const half8 *w2 = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 1) & 3) * HALF_BYTES) + lane;
           half8 n0h = w2[0], n0l = w2[64], n1h = w2[128], n1l = w2[192];
 #pragma unroll
           for (int tp = 0; tp < 8; ++tp) {
             const half8 c0h = n0h, c0l = n0l, c1h = n1h, c1l = n1l;
-            if (tp < 7) {
+            if (tp < 7 && !DEC8_NOREAD) {
               n0h = w2[(4 * tp + 4) * 64];
               n0l = w2[(4 * tp + 5) * 64];
               n1h = w2[(4 * tp + 6) * 64];
               n1l = w2[(4 * tp + 7) * 64];
             }
+#if DEC8_DMA_SPREAD
+            if (!(tp & 1)) issue_dma(4 + (tp >> 1));
+#endif
             Hs[2 * tp] = mfma16(c0h, bhi, Hs[2 * tp]);
             Hs[2 * tp + 1] = mfma16(c1h, bhi, Hs[2 * tp + 1]);
             if (X3) {
@@ -288,7 +337,21 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
               Hs[2 * tp + 1] = mfma16(c1l, bhi, Hs[2 * tp + 1]);
             }
           }
+        };
+#if DEC8_SWAP
+        if (wave >= 4) {
+          phase_b();
+          __builtin_amdgcn_sched_barrier(0);
+          phase_a();
+        } else {
+          phase_a();
+          __builtin_amdgcn_sched_barrier(0);
+          phase_b();
         }
+#else
+        phase_a();
+        phase_b();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         acc_cur[0] = acc_next[0];

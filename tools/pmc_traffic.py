@@ -1,0 +1,52 @@
+"""HBM traffic of the decoder launches INSIDE the benchmark from two rocprofv3 PMC passes
+(FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots"):
+
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d DIR/fetch -- python bench.py ...
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d DIR/write -- python bench.py ...
+  python tools/pmc_traffic.py DIR N_QUERY_POINTS_OF_THOSE_LAUNCHES > profiles/rNN_decoder_traffic.txt
+
+Corrections as the guide prescribes: FETCH_SIZE is in KB and reports half the bytes of wide (16 B per
+lane) streaming reads on gfx950 -> x2 (an upper bound here: not every read of this kernel is a wide
+stream); WRITE_SIZE in KB, uncalibrated.  Also writes profiles/decoder_traffic.json, which bench.py
+reads for `roofline.traffic` (the counters cannot be read from inside the benchmarked process)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def collect(d, counter, kernel_substr):
+    tot, n = 0.0, 0
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                    tot += float(row["Counter_Value"])
+                    n += 1
+    return tot, n
+
+
+def main():
+    d, n_points = sys.argv[1], float(sys.argv[2])
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    kern = "occ_decode"
+    fetch_kb, nf = collect(os.path.join(d, "fetch"), "FETCH_SIZE", kern)
+    write_kb, nw = collect(os.path.join(d, "write"), "WRITE_SIZE", kern)
+    fetch_b = fetch_kb * 1024 * 2          # gfx950: wide streaming reads are tallied at half their size
+    write_b = write_kb * 1024
+    bpq = (fetch_b + write_b) / n_points
+    print("decoder launches: %d (fetch pass) / %d (write pass); %.0f query points in total" % (nf, nw, n_points))
+    print("FETCH_SIZE sum %.0f KB -> %.1f MB after the gfx950 x2 correction for 16-B/lane streaming reads" % (fetch_kb, fetch_b / 1e6))
+    print("WRITE_SIZE sum %.0f KB =  %.1f MB  (logits: %.1f MB + tile padding)" % (write_kb, write_b / 1e6, n_points * 4 / 1e6))
+    print("total %.1f MB / %.2f M points = %.1f B per query point (algorithmic 16 B: 12 in, 4 out; the shared "
+          "round-0 lattice makes the real input ~3 B)" % ((fetch_b + write_b) / 1e6, n_points / 1e6, bpq))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "decoder_traffic.json"), "w") as fh:
+        json.dump({"bytes_per_query": round(bpq, 2),
+                   "source": "profiles/%s_decoder_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes "
+                             "over the decoder launches of bench.py; FETCH x2 gfx950 correction)" % tag}, fh)
+
+
+if __name__ == "__main__":
+    main()
