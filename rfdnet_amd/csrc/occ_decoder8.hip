@@ -18,22 +18,12 @@
 #include "common.h"
 #include "../../include/rfd_occ.h"
 
-#ifndef DEC8_DMA_ALT
-#define DEC8_DMA_ALT 0
-#endif
-#ifndef DEC8_DMA_SPREAD
-#define DEC8_DMA_SPREAD 0
-#endif
-#ifndef DEC8_SWAP
-#define DEC8_SWAP 0
-#endif
-#ifndef DEC8_PRIO
-#define DEC8_PRIO 0
-#endif
-#ifndef DEC8_NOREAD      // timing only: fragments are not re-read from LDS inside phases A / B
+// Timing-only side builds (tools/ab/, results are WRONG on purpose): what do the LDS fragment
+// reads and the LDS-DMA weight stream cost?  profiles/r02_decoder_ablation.txt: -15 % / -10 %.
+#ifndef DEC8_NOREAD
 #define DEC8_NOREAD 0
 #endif
-#ifndef DEC8_NODMA       // timing only: no LDS-DMA transfers after the priming
+#ifndef DEC8_NODMA
 #define DEC8_NODMA 0
 #endif
 
@@ -167,9 +157,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g4 = 4 * (lane >> 4), n = lane & 15;
   unsigned amax16 = 0u;
-#if DEC8_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration otherwise
-#endif
+  // the later-dispatched half of the workgroup loses every issue arbitration against its SIMD
+  // partner otherwise (MI355X_MICROARCH.md "static priority for the younger half"): +0.6 %
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   const int t_begin = blockIdx.x * tiles_per_wg;
   const int t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
@@ -259,22 +249,6 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
         auto issue_dma = [&](int j) {          // piece j (0..7) of this slab's two halves
 #if DEC8_NODMA
           (void)j;
-#elif DEC8_DMA_ALT
-          // only one wave of each SIMD pair issues in a slab (alternating): 16 pieces = frags
-          // 8 (wave & 3) + 0..7 of both halves
-          if ((wave >> 2) == (c & 1)) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int jj = 2 * j + u;          // 0..15
-              const int h = 2 * c + 3 + (jj >> 3);
-              if (h < N_HALVES || has_next) {
-                const int frag = (wave & 3) * 8 + (jj & 7);
-                const int hs = h >= N_HALVES ? h - N_HALVES : h;
-                __builtin_amdgcn_global_load_lds((gbl_void *)(packed + ((size_t)hs * HALF_FRAGS + frag) * 64 + lane),
-                                                 (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, 0);
-              }
-            }
-          }
 #else
           const int h = 2 * c + 3 + (j >> 2);
           if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, j & 3, wave, lane);
@@ -293,11 +267,7 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
               n1h = w[(4 * ks + 6) * 64];
               n1l = w[(4 * ks + 7) * 64];
             }
-#if DEC8_DMA_SPREAD
-            if (!(ks & 1)) issue_dma(ks >> 1);
-#else
             issue_dma(ks);
-#endif
             acc_next[0] = mfma16(w0h, ahi[ks], acc_next[0]);
             acc_next[1] = mfma16(w1h, ahi[ks], acc_next[1]);
             if (X3) {
@@ -309,7 +279,7 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < (DEC8_DMA_SPREAD ? 4 : 8); ++j) issue_dma(j);
+          for (int j = 0; j < 8; ++j) issue_dma(j);
         }
         };
         // ---- phase B: H'[t] += fc_1[16t.., slab mb] a2', sixteen accumulators, two chains at a time
@@ -325,9 +295,6 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
               n1h = w2[(4 * tp + 6) * 64];
               n1l = w2[(4 * tp + 7) * 64];
             }
-#if DEC8_DMA_SPREAD
-            if (!(tp & 1)) issue_dma(4 + (tp >> 1));
-#endif
             Hs[2 * tp] = mfma16(c0h, bhi, Hs[2 * tp]);
             Hs[2 * tp + 1] = mfma16(c1h, bhi, Hs[2 * tp + 1]);
             if (X3) {
@@ -338,20 +305,11 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
             }
           }
         };
-#if DEC8_SWAP
-        if (wave >= 4) {
-          phase_b();
-          __builtin_amdgcn_sched_barrier(0);
-          phase_a();
-        } else {
-          phase_a();
-          __builtin_amdgcn_sched_barrier(0);
-          phase_b();
-        }
-#else
+        // (running the two phases in opposite order on the two waves of a SIMD, spreading the DMA
+        // pieces over both phases, or letting one wave of a pair issue all of them: all within 0.7 %,
+        // the swap -8 % with 28 spilled registers -- profiles/r02_decoder_ablation.txt)
         phase_a();
         phase_b();
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         acc_cur[0] = acc_next[0];
