@@ -62,6 +62,19 @@ __global__ void gemm_pack_w_kernel(int N, int K, int sw, const float *__restrict
   packed[e] = split == 0 ? hi : lo;
 }
 
+// running maximum of |hi| words (two f16 per register): an activation that reaches the f16 limit
+// (|a| 2^sa >= 65504: cvt_pkrtz saturates, the product is silently wrong where the reference's
+// fp32 GEMM is not) raises bit 2 of the device status word, as the decoder does (occ_decoder.hip)
+__device__ __forceinline__ unsigned amax_u16(unsigned acc, unsigned hiw, bool nonneg) {
+  unsigned r;
+  const unsigned a = nonneg ? hiw : (hiw & 0x7fff7fffu);
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(acc), "v"(a));
+  return r;
+}
+__device__ __forceinline__ void flag_overflow(unsigned amax16, unsigned *status) {
+  if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(status, 4u);
+}
+
 __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -79,6 +92,7 @@ struct Args {
   float a_scale, out_scale;     // 2^sa, 2^-(sa+sw)
   float *pool;                  // [M/rows_per_group][N] running max(0, C) per group, or null (row-owner kernel)
   int pool_signed;              // pool holds the plain max (caller initialises it to -inf) instead of max(0, C)
+  unsigned *status;             // device status word (bit 2: an activation left the f16 range)
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
@@ -101,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
   const int m0 = mtile * BM, n0 = ntile * BN;
   const int kiters = g.K / BK;
 
+  unsigned amax16 = 0u;
   // A loader geometry: thread -> (row, 16-wide k half)
   const int arow = t >> 1, akh = t & 1;
   const float *aptr = g.A + (size_t)(m0 + arow) * g.lda + akh * 16;
@@ -124,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
         const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(a0, a1));
         const float r0 = a0 - (float)h2[0], r1 = a1 - (float)h2[1];
         hw[q * 2 + e / 2] = __builtin_bit_cast(unsigned, h2);
+        amax16 = amax_u16(amax16, hw[q * 2 + e / 2], false);
         lw[q * 2 + e / 2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
       }
     }
@@ -191,8 +207,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
     __syncthreads();
   }
 
+  flag_overflow(amax16, g.status);
   // ---- epilogue: scale back, add bias / group bias / residual, ReLU, store
   const int half = lane >> 5, nl = lane & 31;
+  float omax = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -206,9 +224,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
         if (g.gbias) v += g.gbias[(size_t)(m / g.rows_per_group) * g.N + n];
         if (g.R) v += g.R[(size_t)m * g.ldr + n];
         if (g.relu_out) v = v > 0.f ? v : 0.f;
+        omax = __builtin_fmaxf(omax, __builtin_fabsf(v));
         g.C[(size_t)m * g.ldc + n] = v;
       }
     }
+  if (omax * g.a_scale >= 65504.f) atomicOr(g.status, 4u);    // would overflow the next layer's split
 }
 
 
@@ -357,6 +377,7 @@ __device__ __forceinline__ void rows_epilogue(const Args &g, unsigned char *smem
         }
       const float pinit = g.pool_signed ? -__builtin_inff() : 0.f;
       f32x4 pmax = {pinit, pinit, pinit, pinit};
+      float omax = 0.f;
 #pragma unroll 8
       for (int j = 0; j < 16; ++j) {
         const int row = 2 * j + rsel;
@@ -370,9 +391,14 @@ __device__ __forceinline__ void rows_epilogue(const Args &g, unsigned char *smem
           o[e] = __builtin_fmaf(a[e], g.out_scale, add[e]);
           if (g.relu_out) o[e] = o[e] > 0.f ? o[e] : 0.f;
           pmax[e] = o[e] > pmax[e] ? o[e] : pmax[e];
+          omax = __builtin_fmaxf(omax, __builtin_fabsf(o[e]));
         }
         if (g.C) *reinterpret_cast<f32x4 *>(g.C + m * g.ldc + n0 + 128 * p + 4 * l) = o;   // C may be omitted when only the pool is wanted
       }
+      // A STORED value this large cannot be split by the next layer (|a| 2^sa >= 65504).  The watch sits
+      // on the outputs because this kernel's k loop is pinned instruction by instruction: one more VALU
+      // op in it let the scheduler lift a conversion above its vmcnt wait (tools/audit_vmcnt.py).
+      if (g.C && omax * g.a_scale >= 65504.f) atomicOr(g.status, 4u);
       if (g.pool) {
         // fused max-pool over the group's rows (every consumer rectifies the pooled vector, so
         // max(0, .) is what is needed): non-negative floats order like their bit patterns
@@ -592,6 +618,12 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
   g.pool = pool_max;
   g.pool_signed = pool_signed;
   g.gbias_stride = N;
+  RfdWorkspace *ws0;
+  {
+    int rc0 = rfd_get_workspace(&ws0);
+    if (rc0) return rc0;
+  }
+  g.status = ws0->status;
   const bool aligned = !(ldc & 3) && !(ldr & 3) && !((uintptr_t)C & 15) && !((uintptr_t)R & 15) &&
                        !((uintptr_t)bias & 15) && !((uintptr_t)gbias & 15);
   if (M % RM == 0 && N % RN == 0 && N <= RFD_ZEROS_FLOATS && K % 128 == 0 && aligned &&

@@ -23,7 +23,8 @@ __global__ __launch_bounds__(PE_THREADS) void pos_embed_kernel(
     int M, int N, int d, int ldx, int rows_per_group, int rows_per_block,
     const float *__restrict__ x, const float *__restrict__ mask, const float *__restrict__ W,
     int ldw, const float *__restrict__ bias, const float *__restrict__ group,
-    float *__restrict__ out, int ldo) {
+    float *__restrict__ out, int ldo, unsigned *status) {
+  float omax = 0.f;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   for (int n = threadIdx.x * 4; n < N; n += PE_THREADS * 4) {
@@ -46,10 +47,14 @@ __global__ __launch_bounds__(PE_THREADS) void pos_embed_kernel(
 #pragma unroll
         for (int j = 0; j < PE_MAX_D; ++j) acc = __builtin_fmaf(xr[j], w[c][j], acc);
         o[c] = __builtin_fmaf(m, acc + g[c], b[c]);
+        omax = __builtin_fmaxf(omax, __builtin_fabsf(o[c]));
       }
       *reinterpret_cast<pe4 *>(out + (size_t)r * ldo + n) = o;
     }
   }
+  // the consumer is a split-precision GEMM (csrc/gemm_f16x3.hip, activations scaled by 2^4 before
+  // the f16 split): a value beyond 65504 / 16 would be silently saturated there -- say so
+  if (omax * 16.f >= 65504.f) atomicOr(status, 4u);
 }
 
 }  // namespace
@@ -66,10 +71,15 @@ RFD_API int rfd_pos_embed(int M, int N, int d, const float *x, int ldx, const fl
                   hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
+  RfdWorkspace *ws;
+  {
+    int rc = rfd_get_workspace(&ws);
+    if (rc) return rc;
+  }
   const int rows_per_block = 64;
   hipLaunchKernelGGL(pos_embed_kernel, dim3(ceil_div(M, rows_per_block)), dim3(PE_THREADS), 0,
                      (hipStream_t)stream, M, N, d, ldx, rows_per_group, rows_per_block, x, mask, W,
-                     ldw, bias, group, out, ldo);
+                     ldw, bias, group, out, ldo, ws->status);
   RFD_CHECK_LAUNCH();
   return 0;
 }

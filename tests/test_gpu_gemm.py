@@ -158,3 +158,36 @@ def test_fused_group_max_pool_signed(hip):
     pool2 = torch.full((M // T, N), float("-inf"), device="cuda")
     assert gemm.linear(x, w, bias=bias, rows_per_group=T, pool=pool2, pool_signed=True, store=False) is None
     assert torch.equal(pool2, pool)
+
+
+def test_gemm_flags_activations_beyond_the_f16_range(hip):
+    """|a| * 2^4 >= 65504 saturates the f16 split: the library must say so (device status bit 2)
+    instead of returning a silently wrong product.  The tile kernel watches its INPUT and its output;
+    the row-owner kernel (k loop pinned instruction by instruction) and pos_embed watch what they
+    STORE, i.e. the next layer's input."""
+    from rfdnet_amd import gemm
+    w = torch.randn(128, 32, device="cuda") * 0.1
+    x = torch.zeros(128, 32, device="cuda")
+    gemm.linear(x, w)
+    hip.device_status()                           # clean
+    x[3, 5] = -5000.0                              # negative: magnitude counts, not the sign bit
+    gemm.linear(x, w)
+    with pytest.raises(hip.RfdHipError, match="split-precision GEMM"):
+        hip.device_status()
+    x[3, 5] = 4000.0                               # 4000 * 16 = 64000 < 65504: still representable
+    gemm.linear(x, w)
+    hip.device_status()
+    # row-owner kernel: an OUTPUT of 6000 cannot be the next layer's input
+    M, N, K = 256, 256, 128
+    x = torch.zeros(M, K, device="cuda")
+    x[7, 0] = 100.0
+    w = torch.zeros(N, K, device="cuda")
+    w[11, 0] = 10.0
+    y = gemm.linear(x, w)
+    assert abs(float(y[7, 11]) - 1000.0) < 1e-2
+    hip.device_status()
+    w[11, 0] = 60.0
+    y = gemm.linear(x, w)
+    assert abs(float(y[7, 11]) - 6000.0) < 1e-1   # this product is still right ...
+    with pytest.raises(hip.RfdHipError, match="split-precision GEMM"):
+        hip.device_status()                        # ... but the next split layer would saturate on it
