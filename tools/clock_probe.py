@@ -26,5 +26,9 @@ with torch.no_grad():
         for _ in range(10): dec.decode_tiles(pts, tile_prop, table, fcp)
         torch.cuda.synchronize()
     stop = True; th.join()
-for t, s in samples[2:8]:
-    print(s)
+import json, re
+clk, pw = [], []
+for t, s_ in samples[2:]:
+    m = re.search(r'sclk clock speed:": "\((\d+)Mhz', s_); w = re.search(r'Power \(W\)": "([\d.]+)', s_)
+    if m and w: clk.append(int(m.group(1))); pw.append(float(w.group(1)))
+print("PROBE %s kernel=%s: sclk %.0f MHz (min %d max %d), power %.0f W over %d samples" % (os.environ.get("AB_NAME", "base"), os.environ.get("RFD_DECODER_KERNEL", "w8"), sum(clk)/len(clk), min(clk), max(clk), sum(pw)/len(pw), len(clk)))
