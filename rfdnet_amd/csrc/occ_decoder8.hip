@@ -16,6 +16,7 @@
 // pack kernel orders every weight matrix's columns accordingly, so activations never leave
 // the lane (as in the 4-wave kernel).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/rfd_occ.h"
 
 // Timing-only side builds (tools/ab/, results are WRONG on purpose): what do the LDS fragment
@@ -360,7 +361,11 @@ RFD_API int rfd_occ_decode_w8(int n_tiles, const float *pts, const int *tile_pro
   int rc = rfd_get_workspace(&ws);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int ncu = ws->num_cu > 0 ? ws->num_cu : 256;
+  int ncu = ws->num_cu > 0 ? ws->num_cu : 256;
+  // RFD_DECODER_CUS=n: persistent grid of n workgroups (one per CU: 158 KiB of LDS each), leaving the
+  // other CUs to whatever runs on other streams.  Measured: no gain, default = all.
+  static const int cu_limit = getenv("RFD_DECODER_CUS") ? atoi(getenv("RFD_DECODER_CUS")) : 0;
+  if (cu_limit > 0 && cu_limit < ncu) ncu = cu_limit;
   const int tiles_per_wg = ceil_div(n_tiles, ncu);
   const int grid = ceil_div(n_tiles, tiles_per_wg);
   if (mode == RFD_OCC_MODE_F16X3) {
