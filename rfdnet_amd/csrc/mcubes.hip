@@ -18,12 +18,11 @@
 // All K proposals are processed by the same launches; the -1e6 padding shell is
 // virtual (never materialised).  Three passes over K*D^3 lattice points
 // (D = n + 2), workgroup = a run of MC_RUN consecutive points of one proposal.
-// The only per-point state kept in HBM is ONE byte (the cube index of the point's cell)
-// (the cell whose FAR corner, corner 6, is the point -- a point owns the vertices of the three
-// edges that END in it, see above) plus a sparse int32 vertex base for points that own a
-// vertex; prefix sums are two-level
-// (per-workgroup sums -> tiny scan by the caller -> in-workgroup scan recomputed where
-// needed), so no dense int32 count / scan arrays are written or read:
+// The only per-point state kept in HBM is ONE byte -- the cube index of the cell whose FAR
+// corner (corner 6) is the point; a point owns the vertices of the three edges that END in it,
+// see above -- plus a sparse int32 vertex base for points that own a vertex; prefix sums are
+// two-level (per-workgroup sums -> tiny scan by the caller -> in-workgroup scan recomputed
+// where needed), so no dense int32 count / scan arrays are written or read:
 //   classify : point -> code byte; workgroup -> (#vertices, #triangles)
 //   vertices : one vertex per crossed edge, index = workgroup base + in-workgroup scan;
 //              leaves that index in vbase[point] for the triangle pass
