@@ -180,6 +180,15 @@ int rfd_occ_pack_weights_w8(const float *fc0_w, const float *fc1_w, const int *k
 int rfd_occ_decode_w8(int n_tiles, const float *pts, const int *tile_prop, const int *tile_src,
                       const void *packed, const float *fc_p_w, const float *table,
                       const float *fc_out_w, float fc_out_b, float *logits, int mode, void *stream);
+/* The same launch with MISE.update (mise.pyx:87-104, the value / known part) fused into its epilogue:
+ * instead of a tile-ordered logits buffer, query slot s writes values[prop][lin[s]] (prop = tile_prop of
+ * its tile, values / pstate [K][n_per]) and sets pstate[prop][lin[s]] = 2 (known); lin[s] < 0 = padding
+ * slot.  lin is indexed like pts (through tile_src when given).  Replaces rfd_occ_decode_w8 +
+ * rfd_mise_scatter (generator.py:110-117: decode, then mesh_extractor.update). */
+int rfd_occ_decode_scatter_w8(int n_tiles, const float *pts, const int *tile_prop, const int *tile_src,
+                              const void *packed, const float *fc_p_w, const float *table,
+                              const float *fc_out_w, float fc_out_b, const int *lin, float *values,
+                              unsigned char *pstate, long long n_per, int mode, void *stream);
 
 /* ---- fp32-class GEMM on the f16 matrix cores (csrc/gemm_f16x3.hip) -----------------
  * C[M,N] = act(A)[M,K] . W[N,K]^T (+ bias[N]) (+ gbias[m / rows_per_group][N]) (+ R[M,N]),

@@ -147,10 +147,15 @@ class Generator3D(object):
                       cursors.data_ptr(), float(box_size), pts.data_ptr(), lin.data_ptr())
             if self.round_hook is not None:           # e.g. release a host copy behind the long decode
                 self.round_hook(rounds, depth)
-            logits = dec.decode_tiles(pts, tile_prop, table, fc_p_w, tile_src=tile_src)
-            _call("rfd_mise_scatter", dev, n_tiles, res0, depth, tile_prop.data_ptr(),
-                  tile_src.data_ptr() if tile_src is not None else None, lin.data_ptr(),
-                  logits.data_ptr(), values.data_ptr(), pstate.data_ptr())
+            if dec.can_scatter():
+                # MISE.update's value / known part rides in the decoder's epilogue (no logits buffer,
+                # no scatter launch)
+                dec.decode_tiles(pts, tile_prop, table, fc_p_w, tile_src=tile_src, scatter=(lin, values, pstate))
+            else:
+                logits = dec.decode_tiles(pts, tile_prop, table, fc_p_w, tile_src=tile_src)
+                _call("rfd_mise_scatter", dev, n_tiles, res0, depth, tile_prop.data_ptr(),
+                      tile_src.data_ptr() if tile_src is not None else None, lin.data_ptr(),
+                      logits.data_ptr(), values.data_ptr(), pstate.data_ptr())
             _call("rfd_mise_subdivide", dev, K, res0, depth, float(thr), values.data_ptr(),
                   pstate.data_ptr(), vstate.data_ptr())
             n_queries += total

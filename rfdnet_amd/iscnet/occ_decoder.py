@@ -139,17 +139,36 @@ class DecoderCBatchNorm(nn.Module):
             self._fold_key = key
         return occ_fold.fold_table_stacked(self._fold_consts, z, c)
 
-    def decode_tiles(self, pts, tile_prop, table, fc_p_w, mode=None, tile_src=None):
+    def can_scatter(self):
+        """the eight-wave kernel can write MISE's value / known arrays itself (decode_tiles(scatter=...))"""
+        return self.kernel == "w8" and getattr(self, "fuse_scatter", True)
+
+    def decode_tiles(self, pts, tile_prop, table, fc_p_w, mode=None, tile_src=None, scatter=None):
         """pts (n_src_tiles*128,3) f32, tile_prop (n_tiles,) i32 [, tile_src
-        (n_tiles,) i32: which source tile each tile reads] -> logits (n_tiles*128,)."""
+        (n_tiles,) i32: which source tile each tile reads] -> logits (n_tiles*128,).
+        scatter = (lin i32 indexed like pts, values (K,n_per) f32, pstate (K,n_per) u8): the logits go
+        straight to values[prop, lin] and the points are marked known (returns None)."""
         packed, _, _ = self.packed_weights()
         n_tiles = tile_prop.shape[0]
         assert pts.is_contiguous() and pts.dtype == torch.float32
         assert tile_src is not None or pts.shape[0] == n_tiles * TILE
         assert tile_prop.dtype == torch.int32 and table.is_contiguous()
-        logits = torch.empty(n_tiles * TILE, dtype=torch.float32, device=pts.device)
         wo = self.fc_out.weight.detach().reshape(-1).contiguous()
         bo = self._fc_out_bias()
+        if scatter is not None:
+            lin, values, pstate = scatter
+            assert self.can_scatter() and lin.dtype == torch.int32 and lin.shape[0] == pts.shape[0]
+            assert values.dtype == torch.float32 and pstate.dtype == torch.uint8 and values.is_contiguous()
+            with torch.cuda.device(pts.device):
+                rc = _lib.lib().rfd_occ_decode_scatter_w8(
+                    n_tiles, pts.data_ptr(), tile_prop.data_ptr(),
+                    tile_src.data_ptr() if tile_src is not None else None,
+                    packed.data_ptr(), fc_p_w.data_ptr(), table.data_ptr(), wo.data_ptr(), bo,
+                    lin.data_ptr(), values.data_ptr(), pstate.data_ptr(), int(values.shape[1]),
+                    self.mode if mode is None else mode, _lib.current_stream())
+            _lib.check(rc, "rfd_occ_decode_scatter_w8")
+            return None
+        logits = torch.empty(n_tiles * TILE, dtype=torch.float32, device=pts.device)
         with torch.cuda.device(pts.device):
             decode = _lib.lib().rfd_occ_decode_w8 if self.kernel == "w8" else _lib.lib().rfd_occ_decode
             rc = decode(n_tiles, pts.data_ptr(), tile_prop.data_ptr(),

@@ -180,6 +180,22 @@ def test_generator_mise_grid_matches_reference(hip, onet_and_fixture, tag, res0,
     assert flips.mean() < 1e-4
 
 
+def test_scatter_fused_into_the_decoder_gives_the_same_grids(hip, onet_and_fixture):
+    """rfd_occ_decode_scatter_w8 (MISE.update's value / known part in the decoder's epilogue) against
+    rfd_occ_decode_w8 + rfd_mise_scatter: identical value grids, bit for bit, incl. the shared round-0 list"""
+    fx = onet_and_fixture
+    codes = torch.from_numpy(fx["codes"]).cuda()
+    out = []
+    for fuse in (True, False):
+        onet = load_onet_seeded(make_onet(16, 1), fx)
+        assert onet.decoder.kernel == "w8"
+        onet.decoder.fuse_scatter = fuse
+        assert onet.decoder.can_scatter() == fuse
+        out.append(onet.generator.generate_grids(codes, None))
+        hip.device_status()
+    assert torch.equal(out[0], out[1])
+
+
 # ------------------------------------------------------------ marching cubes ----
 from mc_ref import canon, marching_cubes_soup as np_marching_cubes_soup  # noqa: E402
 
