@@ -162,7 +162,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   // NO s_setprio here.  A static priority for the later-dispatched half of the workgroup (waves 4-7,
   // or 0-3) measured +0.6 % -- and, together with an unrelated codegen change, produced wrong 16-point
   // groups in 80-100 % of fresh processes (equal priorities, 0 or 1 for all waves: 0 of 60).  Not
-  // root-caused; profiles/r02_decoder_ablation.txt section 5.
+  // root-caused, but localised: 16 wait states (or a vmcnt(0)) after every global_load_lds make the
+  // failures disappear, so the hazard sits in what the wave issues right after an LDS-DMA while its
+  // SIMD partner out-prioritises it.  profiles/r02_decoder_ablation.txt section 5.
 
   const int t_begin = blockIdx.x * tiles_per_wg;
   const int t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
