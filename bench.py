@@ -441,6 +441,39 @@ def run_job(args, be, rank, world, dist):
     return stats, single
 
 
+def grouping_roofline(device):
+    """HBM figure of the grouping family (north_star: "rocprof HBM GB/s reported for grouping"), measured
+    live with HIP events on the stream the kernel is launched on: QueryAndGroup's fused epilogue
+    (rfd_group_concat) at the SA2 layer's shape (131 channels x 1024 centres x 32 samples from a
+    2048-point table), B = 32 scenes per launch -- one scene (18.4 MB) is launch-bound.  Algorithmic
+    bytes per launch = 4 C M ns written + 4 M ns of indices + the (C, N) table and xyz read once."""
+    import torch
+    from rfdnet_amd.pointnet2_ops import _ext
+    B, N, M, ns, C = 32, 2048, 1024, 32, 128
+    g = torch.Generator(device=device).manual_seed(0)
+    xyz = torch.rand(B, N, 3, device=device, generator=g)
+    ctr = xyz[:, :M].contiguous()
+    feats = torch.randn(B, C, N, device=device, generator=g)
+    idx = _ext.ball_query(ctr, xyz, 0.4, ns)
+    nbytes = B * ((3 + C) * M * ns * 4 + M * ns * 4 + C * N * 4 + N * 12 + M * 12)
+    for _ in range(3):
+        _ext.group_concat(xyz, ctr, feats, idx, 0.4, True, True, False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    it = 10
+    e0.record()
+    for _ in range(it):
+        _ext.group_concat(xyz, ctr, feats, idx, 0.4, True, True, False)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / it
+    ach = nbytes / ms / 1e6
+    return {"bound": "hbm", "kernel": "group_lds_kernel (rfd_group_concat, SA2 shape, 32 scenes per launch)",
+            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
+            "traffic": None, "note": "not on the headline path any more (the fused SA layer never materialises the "
+                                     "grouped tensor); reported because the grouping family is the path's HBM-bound op"}
+
+
 def traffic_per_query():
     """HBM bytes per query point of the decoder from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this benchmark; counters cannot be read from
@@ -522,6 +555,8 @@ def main(argv=None):
                          "note": "algorithmic FLOPs (1 312 768 per query point) over HIP-event time of the decoder "
                                  "launches inside the timed region; f16x3 issues 3x that on the MFMA pipe"},
         }
+        if be.name in ("hip", "stress"):
+            out["roofline_grouping"] = grouping_roofline(be.device)
         if single is not None:
             out["single_scene"] = {"scenes_in_flight": 1, "ms_per_scene": 1e3 * single,
                                    "scenes_per_s": 1.0 / single}
