@@ -100,3 +100,24 @@ def test_synthetic_scene_is_reproducible_and_has_the_awkward_points():
     assert np.array_equal(a, b) and a.shape == (40000, 4) and a.dtype == np.float32
     assert len(np.unique(a, axis=0)) < 40000               # sampled with replacement => duplicates
     assert ((a[:, :3] ** 2).sum(1) <= 1e-3).sum() >= 1     # near-origin points (FPS skip rule)
+
+
+def test_mean_size_array_sources(tmp_path, monkeypatch):
+    """scannet_config.py:21 reads datasets/scannet/scannet_means.npz relative to the working directory; here an
+    explicit array / path wins, then $RFD_MEAN_SIZE_NPZ, then that relative path, else a flagged placeholder."""
+    import numpy as np
+    from rfdnet_amd.iscnet.config import Config, ScannetConfig
+    monkeypatch.delenv("RFD_MEAN_SIZE_NPZ", raising=False)
+    monkeypatch.chdir(tmp_path)
+    assert ScannetConfig().placeholder_sizes
+    arr = np.arange(24, dtype=np.float64).reshape(8, 3) / 10
+    assert np.array_equal(ScannetConfig(arr).mean_size_arr, arr) and not ScannetConfig(arr).placeholder_sizes
+    np.savez(tmp_path / "m.npz", arr)                       # key 'arr_0', like the reference's file
+    assert np.array_equal(Config(mean_size_arr=str(tmp_path / "m.npz")).dataset_config.mean_size_arr, arr)
+    monkeypatch.setenv("RFD_MEAN_SIZE_NPZ", str(tmp_path / "m.npz"))
+    assert np.array_equal(ScannetConfig().mean_size_arr, arr)
+    monkeypatch.delenv("RFD_MEAN_SIZE_NPZ")
+    (tmp_path / "datasets" / "scannet").mkdir(parents=True)
+    np.savez(tmp_path / "datasets" / "scannet" / "scannet_means.npz", arr + 1)
+    c = ScannetConfig()
+    assert np.array_equal(c.mean_size_arr, arr + 1) and not c.placeholder_sizes
