@@ -257,6 +257,10 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
 #else
           const int h = 2 * c + 3 + (j >> 2);
           if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, j & 3, wave, lane);
+          // scheduling fence: keeps the compiler from interleaving the next LDS reads / the next M0 set-up
+          // with this transfer's issue.  Free (+0.4 %), and the one change that made the static-priority
+          // build's wrong 16-point groups disappear (10/10 -> 0/10; profiles/r02_decoder_ablation.txt section 5)
+          asm volatile("s_nop 0" ::: "memory");
 #endif
         };
         auto phase_a = [&]() {
