@@ -154,3 +154,41 @@ def test_meshes_are_closed(scene):
         key = np.sort(e, axis=1)
         _, counts = np.unique(key[:, 0] * (f.max() + 1) + key[:, 1], return_counts=True)
         assert (counts == 2).all()                 # the -1e6 padding shell closes every surface
+
+
+@pytest.mark.parametrize("seed", [11, 23])
+def test_other_scenes_indices_bit_exact_and_meshes_closed(hip, oracle, seed):
+    """Two more 80 000-point scenes through the whole path (other furniture layouts, other near-ties): the
+    FPS chain and the SA1 / SA2 ball queries against the oracle bit for bit, no device status bit, finite
+    grids, closed meshes."""
+    cfg = Config({'data': {'num_point': 80000}, 'generation': {'resolution_0': 32, 'upsampling_steps': 1}})
+    net = ISCNet(cfg)
+    synthetic.load_seeded(net, 10)
+    net = net.cuda().eval()
+    pc_np = synthetic.synthetic_scene(seed=seed, n_points=80000)
+    pc = torch.from_numpy(pc_np[None]).cuda()
+    with torch.no_grad():
+        end_points, ids, grids = net.generate({'point_clouds': pc}, selection='all', return_grids=True)
+    xyz = np.ascontiguousarray(pc_np[None, :, :3])
+    i1 = oracle.furthest_point_sampling(xyz, 2048)
+    assert np.array_equal(end_points['sa1_inds'].cpu().numpy(), i1)
+    x1 = np.ascontiguousarray(xyz[:, i1[0]])
+    i2 = oracle.furthest_point_sampling(x1, 1024)
+    assert np.array_equal(end_points['sa2_inds'].cpu().numpy(), i2)
+    assert np.array_equal(end_points['sa1_xyz'].cpu().numpy(), x1)
+    from rfdnet_amd.pointnet2_ops import _ext
+    idx1 = _ext.ball_query(torch.from_numpy(x1).cuda(), torch.from_numpy(xyz).cuda(), 0.2, 64).cpu().numpy()
+    assert np.array_equal(idx1, oracle.ball_query(x1, xyz, 0.2, 64))
+    assert grids.shape == (256, 65, 65, 65) and torch.isfinite(grids).all()
+    gen = net.completion.generator
+    with torch.no_grad():
+        meshes = gen.extract_meshes(grids[torch.tensor(PICK, device=grids.device)])
+    hip.device_status()
+    for m in meshes:
+        f = m.faces.cpu().numpy().astype(np.int64)
+        if f.shape[0] == 0:
+            continue
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        key = np.sort(e, axis=1)
+        _, counts = np.unique(key[:, 0] * (f.max() + 1) + key[:, 1], return_counts=True)
+        assert (counts == 2).all()
