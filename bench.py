@@ -500,9 +500,14 @@ def main(argv=None):
         StressBackend if args.config == "stress" else HipBackend
     be = cls(args, rank, local_rank, world)
     dist = None
-    if world > 1:
+    # RFD_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL barrier /
+    # all-gather on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 1 bench.py`)
+    if world > 1 or (os.environ.get("RFD_BENCH_FORCE_DIST") == "1" and sharding.launched()):
         import torch.distributed as dist
-        dist.init_process_group(backend=be.dist_backend)
+        kw = {}
+        if be.dist_backend == "nccl":
+            kw["device_id"] = be.device          # bind the communicator to this rank's GPU up front
+        dist.init_process_group(backend=be.dist_backend, **kw)
     stats, single = run_job(args, be, rank, world, dist)
     gathered = sharding.gather_stats(stats, be.device, dist)     # the path's only exchange step
     value_all, t_max = sharding.job_throughput(gathered)

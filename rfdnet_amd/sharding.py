@@ -101,7 +101,7 @@ def gather_stats(stats, device, dist=None):
     if dist is not None and dist.is_initialized() and dist.get_backend() == "gloo":
         device = torch.device("cpu")          # CPU tests / single-GPU dry runs of the N>1 path
     vec = torch.tensor(stats, dtype=torch.float64, device=device)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return vec.view(1, -1).cpu().numpy()
     world = dist.get_world_size()
     out = torch.empty(world * vec.numel(), dtype=torch.float64, device=device)
