@@ -18,12 +18,16 @@ import torch
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, default=None,
+                    help="a reference config file (configs/config_files/ISCNet_test.yaml); its data / model / test / "
+                         "generation blocks and its `weight` list are used, flags below override it")
+    ap.add_argument("--mode", choices=["demo", "test"], default="demo")
     ap.add_argument("--demo_path", type=str, default=None)
     ap.add_argument("--synthetic", type=int, default=None, help="seed of a synthetic ScanNet-like scene")
     ap.add_argument("--weight", type=str, default=None)
     ap.add_argument("--out", type=str, default="out/demo")
-    ap.add_argument("--resolution_0", type=int, default=32)
-    ap.add_argument("--upsampling_steps", type=int, default=0)          # ISCNet_test.yaml:62-63
+    ap.add_argument("--resolution_0", type=int, default=None)
+    ap.add_argument("--upsampling_steps", type=int, default=None)       # ISCNet_test.yaml:62-63 (32, 0)
     ap.add_argument("--selection", choices=["nms", "all", "objectness"], default="nms")
     ap.add_argument("--mean_size_npz", type=str, default=None,
                     help="class mean sizes (the reference's datasets/scannet/scannet_means.npz); default: "
@@ -34,8 +38,18 @@ def main():
     from rfdnet_amd.iscnet.config import Config
     from rfdnet_amd.iscnet.network import ISCNet
 
-    cfg = Config({'generation': {'resolution_0': args.resolution_0, 'upsampling_steps': args.upsampling_steps}},
-                 mean_size_arr=args.mean_size_npz)
+    gen = {k: v for k, v in (('resolution_0', args.resolution_0), ('upsampling_steps', args.upsampling_steps))
+           if v is not None}
+    if args.config:
+        cfg = Config.from_yaml(args.config, mode=args.mode, overrides={'generation': gen},
+                               mean_size_arr=args.mean_size_npz)
+        if not args.weight and cfg.config.get('weight'):
+            import os
+            w = cfg.config['weight'][0] if isinstance(cfg.config['weight'], (list, tuple)) else cfg.config['weight']
+            if os.path.exists(w):
+                args.weight = w
+    else:
+        cfg = Config({'generation': gen}, mean_size_arr=args.mean_size_npz)
     net = ISCNet(cfg)
     if args.weight:
         ckpt = torch.load(args.weight, map_location="cpu")

@@ -85,6 +85,42 @@ class Config(object):
                 self.config[sect] = kv
         self.dataset_config = ScannetConfig(mean_size_arr)
         self.eval_config = {'dataset_config': self.dataset_config}
+        self._mount_eval_config()
+
+    def _mount_eval_config(self):
+        """configs/config_utils.py:131-149 mount_external_config: the `val` / `test` block of the YAML
+        becomes the dictionary parse_predictions reads (`eval_overrides` = what differs from the defaults)."""
+        ev = self.config.get('val', self.config.get('test')) or {}
+        m = {}
+        if 'faster_eval' in ev:
+            m['remove_empty_box'] = not ev['faster_eval']
+        for src, dst in (('use_3d_nms', 'use_3d_nms'), ('nms_iou', 'nms_iou'), ('use_old_type_nms', 'use_old_type_nms'),
+                         ('use_cls_nms', 'cls_nms'), ('per_class_proposal', 'per_class_proposal'),
+                         ('conf_thresh', 'conf_thresh')):
+            if src in ev:
+                m[dst] = ev[src]
+        self.eval_overrides = m
+        self.eval_config.update(m)
+
+    @classmethod
+    def from_yaml(cls, path, mode='demo', overrides=None, mean_size_arr=None):
+        """Read one of the reference's own config files (configs/config_files/ISCNet_test.yaml: same keys,
+        configs/config_utils.py:83-97 read_to_dict) and set `mode` as main.py:21 / config_utils.py:99-115 do.
+        Keys this path does not use (device, log, dataset paths) are kept in `.config` untouched."""
+        import yaml
+        with open(path) as f:
+            doc = yaml.safe_load(f) or {}
+        cfg = cls(doc, mean_size_arr=mean_size_arr)
+        cfg.config['mode'] = mode
+        for sect, kv in (overrides or {}).items():
+            if isinstance(kv, dict):
+                cfg.config.setdefault(sect, {}).update(kv)
+            else:
+                cfg.config[sect] = kv
+        if mode not in cfg.config or 'phase' not in (cfg.config.get(mode) or {}):
+            raise KeyError("config %s has no `%s: {phase: ...}` block" % (path, mode))
+        cfg._mount_eval_config()
+        return cfg
 
     def log_string(self, s):
         print(s)

@@ -121,3 +121,56 @@ def test_mean_size_array_sources(tmp_path, monkeypatch):
     np.savez(tmp_path / "datasets" / "scannet" / "scannet_means.npz", arr + 1)
     c = ScannetConfig()
     assert np.array_equal(c.mean_size_arr, arr + 1) and not c.placeholder_sizes
+
+
+REF_YAML = "/root/reference/configs/config_files/ISCNet_test.yaml"
+
+
+def test_config_from_a_reference_style_yaml(tmp_path):
+    """Config.from_yaml reads the reference's config FILE FORMAT (keys of configs/config_files/ISCNet_test.yaml),
+    sets the mode like main.py and mounts the eval dictionary like config_utils.mount_external_config."""
+    from rfdnet_amd.iscnet.config import Config
+    from rfdnet_amd.iscnet.network import ISCNet
+    y = tmp_path / "cfg.yaml"
+    y.write_text("""
+method: ISCNet
+weight: ['out/pretrained_models/pretrained_weight.pth']
+seed: 10
+device: {use_gpu: True, gpu_ids: '0', num_workers: 0}
+data: {dataset: scannet, num_point: 40000, num_target: 256, vote_factor: 1, cluster_sampling: seed_fps,
+       no_height: False, use_color_detection: False, use_color_completion: False, hidden_dim: 512, c_dim: 512,
+       z_dim: 32, threshold: 0.5, use_cls_for_completion: False, skip_propagate: True}
+model:
+  backbone: {method: Pointnet2Backbone, loss: Null}
+  voting: {method: VotingModule, loss: Null}
+  detection: {method: ProposalModule, loss: DetectionLoss}
+  skip_propagation: {method: SkipPropagation, loss: Null}
+  completion: {method: ONet, loss: ONet_Loss, weight: 0.005}
+test: {phase: 'completion', batch_size: 1, use_cls_nms: False, use_3d_nms: True, faster_eval: True, nms_iou: 0.3,
+       use_old_type_nms: False, per_class_proposal: True, conf_thresh: 0.07}
+generation: {generate_mesh: True, resolution_0: 16, upsampling_steps: 2, use_sampling: False, refinement_step: 0,
+             simplify_nfaces: Null, dump_threshold: 0.4, dump_results: True}
+demo: {phase: 'completion'}
+log: {vis_path: visualization, path: out/iscnet}
+""")
+    cfg = Config.from_yaml(str(y), mode="demo")
+    assert cfg.config["mode"] == "demo" and cfg.config["data"]["num_point"] == 40000
+    assert cfg.config["generation"]["resolution_0"] == 16 and cfg.config["generation"]["dump_threshold"] == 0.4
+    assert cfg.eval_overrides == {"remove_empty_box": False, "use_3d_nms": True, "nms_iou": 0.3,
+                                  "use_old_type_nms": False, "cls_nms": False, "per_class_proposal": True,
+                                  "conf_thresh": 0.07}
+    net = ISCNet(cfg)                                        # builds the five sub-networks by registry name
+    assert [n for n, _ in net.named_children()] == ["backbone", "voting", "detection", "skip_propagation", "completion"]
+    assert net.completion.generator.resolution0 == 16 and net.completion.generator.upsampling_steps == 2
+    cfg2 = Config.from_yaml(str(y), mode="test", overrides={"generation": {"upsampling_steps": 0}})
+    assert cfg2.config["mode"] == "test" and cfg2.config["generation"]["upsampling_steps"] == 0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="reference checkout not present")
+def test_the_reference_config_file_itself_loads():
+    from rfdnet_amd.iscnet.config import Config, DEFAULT_CONFIG
+    cfg = Config.from_yaml(REF_YAML, mode="demo")
+    for sect in ("data", "generation"):
+        for k, v in DEFAULT_CONFIG[sect].items():
+            assert cfg.config[sect][k] == v, (sect, k)       # our defaults ARE that file's values
+    assert cfg.eval_overrides["cls_nms"] is True and cfg.eval_overrides["remove_empty_box"] is True
