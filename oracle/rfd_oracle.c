@@ -47,7 +47,7 @@
 
 /* nvcc -fmad=true evaluation order of a*a + b*b + c*c (see header).
  * ORACLE_SUMSQ_VARIANT builds the two other orders a compiler could plausibly pick, ONLY to
- * measure how much of the output depends on the assumption (tools/fma_order_report.py,
+ * measure how much of the output depends on the assumption (tests/fma_order_report.py,
  * tests/test_fma_order.py); the shipped oracle and the HIP kernels use variant 0. */
 #ifndef ORACLE_SUMSQ_VARIANT
 #define ORACLE_SUMSQ_VARIANT 0

@@ -7,7 +7,7 @@ orders a compiler could plausibly pick (1: fma(a,a,fma(b,b,c*c)); 2: no contract
 what changes: FPS indices (a single different pick changes everything after it, so the first
 diverging round is reported too), ball-query rows, three_nn picks.
 
-  python tools/fma_order_report.py [--small]      -> table on stdout (profiles/r02_fma_order.txt)
+  python tests/fma_order_report.py [--small]      -> table on stdout (profiles/r02_fma_order.txt)
 """
 import os
 import sys

@@ -1,6 +1,6 @@
 """CPU: how much of the FPS / ball-query / three_nn output depends on the assumed nvcc contraction
 of a*a + b*b + c*c (oracle/rfd_oracle.c header)?  The oracle is rebuilt with the two other
-plausible orders and the differing outputs are COUNTED (tools/fma_order_report.py; the full table
+plausible orders and the differing outputs are COUNTED (tests/fma_order_report.py; the full table
 for the config-2 / config-0 / F_NET scenes is committed as profiles/r02_fma_order.txt).
 The distance tests themselves (ball query, three_nn on identical inputs) must not move at all; an
 FPS chain may swap picks only at a near-tie -- a handful of indices, never a different sampling."""
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def test_alternative_fma_orders_change_at_most_near_ties(oracle):
