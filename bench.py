@@ -272,6 +272,27 @@ class HipBackend(object):
 
     def final_check(self):
         self._lib.device_status()
+        self.selfcheck = self.decoder_selfcheck(self.dec if hasattr(self, "dec") else self.nets[0].completion.decoder)
+
+    def decoder_selfcheck(self, dec):
+        """After the timed region: the same multi-proposal ragged launch twice -- the two results must be
+        bit-identical (a race shows up as one wave's 16 points differing in one of the runs; the static-priority
+        build of round 2 failed exactly this check, profiles/r02_decoder_ablation.txt section 5)."""
+        torch = self.torch
+        g = torch.Generator(device=self.device).manual_seed(5)
+        K, T = 8, 1024
+        p = (torch.rand(K, T, 3, device=self.device, generator=g) - 0.5) * 1.1
+        c = torch.randn(K, 512, device=self.device, generator=g)
+        z = torch.zeros(K, 32, device=self.device)
+        with torch.no_grad():
+            table, fcp = dec.fold(z, c)
+            tile_prop = torch.arange(K, dtype=torch.int32, device=self.device).repeat_interleave(T // 128)
+            pts = p.reshape(-1, 3).contiguous()
+            runs = [self.timers[0]._orig(pts, tile_prop, table, fcp) for _ in range(4)]
+        same = all(torch.equal(runs[0], r) for r in runs[1:])
+        if not same:
+            raise RuntimeError("decoder self-check: repeated launches on the same input differ")
+        return "4 launches of 8 x 1024 points bit-identical"
 
     def kernel_name(self):
         return "%s<%d>" % ("occ_decode8_kernel" if self.nets[0].completion.decoder.kernel == "w8"
@@ -544,7 +565,7 @@ def main(argv=None):
                        "vertices_per_scene": int(gathered[:, F("n_vertices")].sum() / per),
                        "scenes_in_flight_per_gpu": be.S * be.NB, "scenes_per_forward": be.NB,
                        "scenes_per_step": be.S * be.NB * world, "scenes_done": int(scenes_total),
-                       "scenes_failed": failed,
+                       "scenes_failed": failed, "decoder_selfcheck": getattr(be, "selfcheck", None),
                        "parallelism": "scenes sharded across GPUs (scene i -> rank i mod %d), dp%d; %d forward "
                                       "passes of %d scene(s) in flight per GPU" % (world, world, be.S, be.NB)},
             "roofline": {"bound": "mfma", "kernel": be.kernel_name(),
