@@ -244,15 +244,15 @@ class HipBackend(object):
         with torch.no_grad():
             end_points, proposal_features = net.detect(pc)
             sel = net.select_proposals(end_points, 'all', pc)
-            codes = net.object_codes(end_points, proposal_features, sel, pc)
-            cls = net.cls_codes(end_points, sel)
             gen = net.completion.generator
             # the previous scene's PCIe copy rides behind the first (longest) decode launch
             gen.round_hook = lambda r, depth: sink.start_pending() if r == 0 else None
-            meshes = gen.generate_mesh(codes, cls)
+            # skip propagation -> codes -> completion + the stream's status word (FPS time-out -> raises; an
+            # f16-range flag -> one re-run of the stage at the fallback activation scale, raises only if that
+            # overflows too)
+            meshes = net.reconstruct(end_points, proposal_features, sel, pc)
             if self.args.upsampling_steps == 0:
                 sink.start_pending()
-        net.check_device_status(pc.device)                           # FPS time-out / f16 overflow -> raises
         v, f, _, _ = gen.last_buffers                              # all K meshes: one vertex / one face buffer
         sink.push(v, f)
         return len(meshes), int(v.shape[0]), int(f.shape[0]), gen.stats.get('n_queries', 0)
@@ -297,6 +297,55 @@ class HipBackend(object):
     def kernel_name(self):
         return "%s<%d>" % ("occ_decode8_kernel" if self.nets[0].completion.decoder.kernel == "w8"
                            else "occ_decode_kernel", 3 if self.args.mode == "f16x3" else 1)
+
+    def parity_sample(self, picks=(0, 97, 255)):
+        """After the timed region, rank 0, N=1 (beside the CPU baseline): BASELINE.json configs[4]'s parity figure
+        on a few proposals of scene 0 -- the CPU path (oracle decoder -> oracle octree MISE -> oracle marching
+        cubes; oracle/parity.py, checker only) against this run's HIP value grids and meshes: occupancy IoU of
+        `grid >= threshold`, face counts, vertex Hausdorff distance in cells."""
+        import numpy as np
+        from collections import OrderedDict
+        from oracle import oracle, parity
+        torch = self.torch
+        net = self.nets[0]
+        gen = net.completion.generator
+        if gen.upsampling_steps == 0:
+            return None
+        pc = self.scenes[0][None]
+        with torch.no_grad():
+            end_points, feats = net.detect(pc)
+            sel = net.select_proposals(end_points, 'all', pc)
+            codes = net.object_codes(end_points, feats, sel, pc)
+            cls = net.cls_codes(end_points, sel)
+            grids = gen.generate_grids(codes, cls)
+            thr = gen.logit_threshold()
+            inside = (grids >= thr).flatten(1).float().mean(1)
+            thin = int(torch.where(inside > 0, inside, torch.ones_like(inside)).argmin().item())
+            picks = list(dict.fromkeys(list(picks) + [thin]))
+            idx = torch.tensor(picks, device=codes.device)
+            meshes = gen.extract_meshes(grids[idx])
+        model = net.completion
+        blob = oracle.decoder_param_blob(OrderedDict((k, v.detach().cpu().numpy())
+                                                     for k, v in model.decoder.state_dict().items()))
+        c_in = codes[idx]
+        if getattr(model, 'use_cls_for_completion', False):
+            c_in = torch.cat([c_in, cls[idx]], dim=-1)
+        z = model.get_z_from_prior((len(picks),), sample=gen.sample, device=codes.device).cpu().numpy()
+        c_np = c_in.cpu().numpy()
+        rows = []
+        for j, k in enumerate(picks):
+            cpu_grid, n_q = parity.cpu_value_grid(blob, z[j], c_np[j], gen.resolution0, gen.upsampling_steps, thr,
+                                                  gen.padding)
+            r = parity.compare(grids[k].cpu().numpy(), meshes[j].vertices.cpu().numpy(),
+                               meshes[j].faces.cpu().numpy(), cpu_grid, thr, gen.padding)
+            r["proposal"], r["cpu_queries"] = int(k), int(n_q)
+            rows.append(r)
+        return {"what": "CPU path (oracle decoder + octree MISE + marching cubes) vs HIP path, scene 0, proposals %s"
+                        % picks,
+                "min_iou": min(r["iou"] for r in rows), "flips": sum(r["flips"] for r in rows),
+                "max_abs_dlogit": max(r["max_abs_dlogit"] for r in rows),
+                "faces_equal": all(r["faces_hip"] == r["faces_cpu"] for r in rows),
+                "max_vertex_hausdorff_cells": max(r["hausdorff_cells"] for r in rows), "per_proposal": rows}
 
 
 class StressBackend(HipBackend):
@@ -593,6 +642,10 @@ def main(argv=None):
             else:
                 out["cpu_baseline"] = cpu_baseline.run(args.points, args.resolution0, args.upsampling_steps,
                                                        int(dec_pts / per), int(gathered[0, F("n_meshes")] / per))
+                par = be.parity_sample()
+                if par is not None:
+                    out["config"]["parity_iou"] = par["min_iou"]
+                    out["parity"] = par
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--mean_size_npz", type=str, default=None,
                     help="class mean sizes (the reference's datasets/scannet/scannet_means.npz); default: "
                          "$RFD_MEAN_SIZE_NPZ or that path relative to the working directory")
+    ap.add_argument("--allow-placeholder-sizes", action="store_true",
+                    help="synthetic runs only: let --selection nms decode boxes with placeholder class mean sizes when "
+                         "no scannet_means.npz is available (the reference fails hard on the missing file; so does this "
+                         "path without the flag)")
     args = ap.parse_args()
 
     from rfdnet_amd import io, synthetic
@@ -50,6 +54,8 @@ def main():
                 args.weight = w
     else:
         cfg = Config({'generation': gen}, mean_size_arr=args.mean_size_npz)
+    if args.allow_placeholder_sizes:
+        cfg.eval_overrides['allow_placeholder_sizes'] = True
     net = ISCNet(cfg)
     if args.weight:
         ckpt = torch.load(args.weight, map_location="cpu")

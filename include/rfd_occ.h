@@ -215,10 +215,11 @@ int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *pac
  *   out[r][n] = bias[n] + mask[r] * (sum_{j<d} x[r][j] W[n][j] + group[r / rows_per_group][n])
  * x [M][ldx] (first d <= 8 columns), mask [M], W [N][ldw] (first d columns), bias [N],
  * group [M / rows_per_group][N] = box_feature . W[:, d:]^T, out [M][ldo] (may be a column
- * window of a wider row-major buffer).  N % 4 == 0, ldo % 4 == 0. */
+ * window of a wider row-major buffer).  N % 4 == 0, ldo % 4 == 0.  sa = the activation scale exponent of
+ * the split-precision GEMM that consumes `out` (status bit 4 when |out| 2^sa would leave the f16 range). */
 int rfd_pos_embed(int M, int N, int d, const float *x, int ldx, const float *mask,
                   const float *W, int ldw, const float *bias, const float *group,
-                  int rows_per_group, float *out, int ldo, void *stream);
+                  int rows_per_group, float *out, int ldo, int sa, void *stream);
 
 #ifdef __cplusplus
 }

@@ -50,7 +50,7 @@ SIGNATURES = {
     "rfd_mc_classify": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f],
     "rfd_mc_emit": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f, _f, _f, _f],
     "rfd_mc_blocks": [_i],
-    "rfd_pos_embed": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f],
+    "rfd_pos_embed": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _f],
 }
 _RESTYPES = {
     "rfd_last_error_string": C.c_char_p,
@@ -123,12 +123,30 @@ def current_stream():
 def _raise_status(st):
     if st < 0:
         raise RfdHipError("rfd_device_status failed")
+    msgs = []
     if st & 1:
-        raise RfdHipError("FPS inter-workgroup exchange timed out")
+        msgs.append("FPS inter-workgroup exchange timed out")
     if st & 2:
-        raise RfdHipError("occupancy decoder: activation exceeded the f16 range")
+        msgs.append("occupancy decoder: activation exceeded the f16 range")
     if st & 4:
-        raise RfdHipError("split-precision GEMM: activation exceeded the f16 range")
+        msgs.append("split-precision GEMM: activation exceeded the f16 range")
+    if msgs:
+        e = RfdHipError("; ".join(msgs))
+        e.status = st
+        raise e
+    return st
+
+
+def raise_status(st):
+    """Raise for the flags in `st` (as returned by *_status_bits)."""
+    return _raise_status(st)
+
+
+def stream_status_bits():
+    """The current stream's status word (waits for that stream, clears the word), no exception for set flags."""
+    st = lib().rfd_stream_status(current_stream())
+    if st < 0:
+        raise RfdHipError("rfd_stream_status failed")
     return st
 
 

@@ -32,7 +32,9 @@ void rfd_set_error(const char *where, hipError_t e);
 // status word).  Allocated once per device, never freed.
 struct RfdWorkspace {
   unsigned long long *fps_slots;  // FPS_RING regions of FPS_REGION_GRANULES
-  unsigned *status;               // device status word (0 = OK)
+  unsigned *status;               // RFD_STATUS_SLOTS device status words (0 = OK): one per stream that has launched
+                                  // a flag-raising kernel (rfd_status_word), slot 0 = overflow / default
+  std::atomic<void *> status_owner[64];   // stream handle owning each slot (nullptr = free); slot 0 is shared
   float *zeros;                   // RFD_ZEROS_FLOATS zeros (stand-in for absent bias vectors)
   std::atomic<unsigned> ring_pos;   // callers may come from several host threads / streams
   int num_cu;                     // multiprocessor count of the device
@@ -41,7 +43,11 @@ constexpr int RFD_ZEROS_FLOATS = 16384;
 constexpr int FPS_RING = 16;
 constexpr int FPS_MAX_WG = 256;                         // co-resident WGs/launch
 constexpr int FPS_REGION_GRANULES = FPS_MAX_WG * 2 * 5; // [wg][parity][field]
+constexpr int RFD_STATUS_SLOTS = 64;
 int rfd_get_workspace(RfdWorkspace **ws);
+// The status word kernels launched on `stream` raise their flags in.  Scenes in flight on different streams
+// must not see (or clear) each other's flags: rfd_stream_status(stream) reads and resets this word only.
+unsigned *rfd_status_word(RfdWorkspace *ws, hipStream_t stream);
 
 // ---- arithmetic contract ------------------------------------------------------
 // a*a + b*b + c*c as nvcc -fmad=true contracts it (see oracle/rfd_oracle.c

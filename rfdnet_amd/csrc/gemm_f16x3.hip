@@ -398,7 +398,8 @@ __device__ __forceinline__ void rows_epilogue(const Args &g, unsigned char *smem
       // A STORED value this large cannot be split by the next layer (|a| 2^sa >= 65504).  The watch sits
       // on the outputs because this kernel's k loop is pinned instruction by instruction: one more VALU
       // op in it let the scheduler lift a conversion above its vmcnt wait (tools/audit_vmcnt.py).
-      if (g.C && omax * g.a_scale >= 65504.f) atomicOr(g.status, 4u);
+      // (pool-only launches included: the pooled maximum feeds the next split GEMM as well)
+      if (omax * g.a_scale >= 65504.f) atomicOr(g.status, 4u);
       if (g.pool) {
         // fused max-pool over the group's rows (every consumer rectifies the pooled vector, so
         // max(0, .) is what is needed): non-negative floats order like their bit patterns
@@ -623,7 +624,7 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
     int rc0 = rfd_get_workspace(&ws0);
     if (rc0) return rc0;
   }
-  g.status = ws0->status;
+  g.status = rfd_status_word(ws0, (hipStream_t)stream);
   const bool aligned = !(ldc & 3) && !(ldr & 3) && !((uintptr_t)C & 15) && !((uintptr_t)R & 15) &&
                        !((uintptr_t)bias & 15) && !((uintptr_t)gbias & 15);
   if (M % RM == 0 && N % RN == 0 && N <= RFD_ZEROS_FLOATS && K % 128 == 0 && aligned &&

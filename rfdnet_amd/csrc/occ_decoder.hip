@@ -505,11 +505,11 @@ RFD_API int rfd_occ_decode(int n_tiles, const float *pts, const int *tile_prop,
   if (mode == RFD_OCC_MODE_F16X3) {
     hipLaunchKernelGGL(occ_decode_kernel<3>, dim3(grid), dim3(256), 0, s, n_tiles, pts,
                        tile_prop, tile_src, (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b,
-                       logits, ws->status, tiles_per_wg);
+                       logits, rfd_status_word(ws, s), tiles_per_wg);
   } else if (mode == RFD_OCC_MODE_F16X1) {
     hipLaunchKernelGGL(occ_decode_kernel<1>, dim3(grid), dim3(256), 0, s, n_tiles, pts,
                        tile_prop, tile_src, (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b,
-                       logits, ws->status, tiles_per_wg);
+                       logits, rfd_status_word(ws, s), tiles_per_wg);
   } else {
     rfd_set_error("rfd_occ_decode: unknown mode", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;

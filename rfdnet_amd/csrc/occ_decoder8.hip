@@ -17,6 +17,7 @@
 // the lane (as in the 4-wave kernel).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/rfd_occ.h"
 
 // Timing-only side builds (tools/ab/, results are WRONG on purpose): what do the LDS fragment
@@ -26,6 +27,28 @@
 #endif
 #ifndef DEC8_NODMA
 #define DEC8_NODMA 0
+#endif
+// Correctness experiments (tools/ab/prio_check.py, profiles/r03_decoder_hazard.txt):
+//   DEC8_ROT   1 = weight-fragment prefetch through three rotating register sets whose disjointness from the
+//                  operands of the previous k-step's MFMAs is guaranteed by the asm constraints (shipped);
+//              0 = round 2's compiler-allocated two-set prefetch (the form that failed under static priority)
+//   DEC8_FENCE 1 = round 2's scheduling fence after every LDS-DMA issue
+//   DEC8_PRIO  1 = static s_setprio 1 for waves 4-7 (the arrangement that exposed the failure)
+#ifndef DEC8_ROT
+#define DEC8_ROT 1
+#endif
+#ifndef DEC8_FENCE
+#define DEC8_FENCE 0
+#endif
+#ifndef DEC8_SB
+#define DEC8_SB 1
+#endif
+#ifndef DEC8_PRIO
+#define DEC8_PRIO 0
+#endif
+// cache policy bits of the LDS-DMA weight stream (aux operand of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef DEC8_DMA_AUX
+#define DEC8_DMA_AUX 0
 #endif
 
 namespace {
@@ -137,8 +160,88 @@ __device__ __forceinline__ void dma_piece8(const half8 *__restrict__ packed, uns
                                            int wave, int lane) {
   const int frag = wave * 4 + j;
   const int hs = h >= N_HALVES ? h - N_HALVES : h;
+#if DEC8_ROT == 0
   __builtin_amdgcn_global_load_lds((gbl_void *)(packed + ((size_t)hs * HALF_FRAGS + frag) * 64 + lane),
-                                   (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, 0);
+                                   (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, DEC8_DMA_AUX);
+#else
+  // wave-uniform part computed apart from the lane part (SGPR pair + one 32-bit lane offset; no reassociation into a
+  // per-piece 64-bit VGPR sum chain)
+  unsigned long long b64 = (unsigned long long)packed + ((size_t)hs * HALF_FRAGS + frag) * 1024;
+  asm("" : "+s"(b64));
+  const char *base = reinterpret_cast<const char *>(b64);
+  __builtin_amdgcn_global_load_lds((gbl_void *)(base + (unsigned)(lane * 16)),
+                                   (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, DEC8_DMA_AUX);
+#endif
+}
+
+// ---- weight-fragment prefetch with PROVABLY disjoint destinations --------------------------------------------
+// A k-step's four fragments (hi/lo of two channel tiles) are fetched one step ahead.  Round 2 let the compiler
+// place them: it reused the registers the previous step's MFMAs had just read as SrcA (0-6 wait states earlier),
+// and a build with unequal wave priorities returned wrong 16-point groups (profiles/r02_decoder_ablation.txt
+// section 5, profiles/r03_decoder_hazard.txt).  Now THREE sets rotate -- in use (cur), in flight (nxt), last read
+// (prv) -- and the structure, not the allocator's mood, keeps them apart:
+//   * step_fence(): nothing is scheduled across a k-step boundary (hipcc otherwise sinks the register-only MFMAs
+//     of step k-2 below the prefetch of step k);
+//   * keep_alive(cur, prv) at the END of every step: both sets stay allocated for the whole step, so neither the
+//     prefetch destinations nor any other load issued in step k (conditioning-table reads) can be given a register
+//     that the MFMAs of step k or k-1 read.  A destination was therefore last read >= one whole k-step (six
+//     MFMAs) earlier.  tools/audit_mfma_war.py checks exactly that on the generated assembly (CPU suite).
+// DEC8_ROT 1: the prefetch is an asm statement (invisible to hipcc's lgkmcnt bookkeeping: frag_wait() = lgkmcnt(0)
+// naming the destinations stands before the first use; LDS returns in order, so hipcc's own counted waits only
+// ever over-wait).  DEC8_ROT 2: plain loads, hipcc counts them and pads MFMA-SrcC write-after-read states itself.
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+struct Frag4 {
+  half8 h0, l0, h1, l1;
+};
+
+__device__ __forceinline__ void keep_alive(const Frag4 &a, const Frag4 &b) {
+  asm volatile("" ::"v"(a.h0), "v"(a.l0), "v"(a.h1), "v"(a.l1), "v"(b.h0), "v"(b.l0), "v"(b.h1), "v"(b.l1));
+}
+__device__ __forceinline__ void keep_alive(const Frag4 &a) {
+  asm volatile("" ::"v"(a.h0), "v"(a.l0), "v"(a.h1), "v"(a.l1));
+}
+
+#if DEC8_ROT == 2
+template <int OFF>
+__device__ __forceinline__ void frag_issue(Frag4 &d, const half8 *base) {
+  const half8 *w = base + OFF / 16;
+  d.h0 = w[0];
+  d.l0 = w[64];
+  d.h1 = w[128];
+  d.l1 = w[192];
+}
+__device__ __forceinline__ void frag_wait(Frag4 &d) { (void)d; }
+#else
+template <int OFF>
+__device__ __forceinline__ void frag_issue(Frag4 &d, const half8 *base) {
+  const unsigned addr = lds_addr(base);
+  asm volatile(
+      "ds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c6\n\t"
+      "ds_read_b128 %2, %4 offset:%c7\n\tds_read_b128 %3, %4 offset:%c8"
+      : "=&v"(d.h0), "=&v"(d.l0), "=&v"(d.h1), "=&v"(d.l1)
+      : "v"(addr), "i"(OFF), "i"(OFF + 1024), "i"(OFF + 2048), "i"(OFF + 3072));
+}
+__device__ __forceinline__ void frag_wait(Frag4 &d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d.h0), "+v"(d.l0), "+v"(d.h1), "+v"(d.l1));
+}
+#endif
+
+// Nothing is scheduled across a k-step boundary (see above).
+__device__ __forceinline__ void step_fence() {
+#if DEC8_SB
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 
 template <int TERMS>
@@ -159,12 +262,13 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g4 = 4 * (lane >> 4), n = lane & 15;
   unsigned amax16 = 0u;
-  // NO s_setprio here.  A static priority for the later-dispatched half of the workgroup (waves 4-7,
-  // or 0-3) measured +0.6 % -- and, together with an unrelated codegen change, produced wrong 16-point
-  // groups in 80-100 % of fresh processes (equal priorities, 0 or 1 for all waves: 0 of 60).  Not
-  // root-caused, but localised: 16 wait states (or a vmcnt(0)) after every global_load_lds make the
-  // failures disappear, so the hazard sits in what the wave issues right after an LDS-DMA while its
-  // SIMD partner out-prioritises it.  profiles/r02_decoder_ablation.txt section 5.
+  // No static priority in the shipped build (+0.6 % at best).  Round 2: a static priority for the later-dispatched
+  // half of the workgroup, together with the compiler-placed fragment prefetch (DEC8_ROT 0), produced wrong
+  // 16-point groups in 80-100 % of fresh processes -- profiles/r02_decoder_ablation.txt section 5,
+  // profiles/r03_decoder_hazard.txt for what round 3 found and why the prefetch is now built as it is.
+#if DEC8_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
   const int t_begin = blockIdx.x * tiles_per_wg;
   const int t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
@@ -217,6 +321,33 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
       // ---- block input a' = relu(S0' H' + T0'), fused with fc_0 of output block 0: k-step ks
       // needs only channel tiles 2ks, 2ks+1, so k-step ks+1 is converted under its MFMAs
       f32x4 acc_cur[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#if DEC8_ROT
+      {
+        const half8 *a0 = reinterpret_cast<const half8 *>(s_slots + ((2 * blk * 8) & 3) * HALF_BYTES) + lane;
+        Frag4 fs[3];
+        frag_issue<0>(fs[0], a0);
+        act_kstep<X3>(Hs[0], Hs[1], S0, T0, g4, ahi[0], alo[0], amax16);
+        static_for<0, 8>([&](auto kc) {
+          constexpr int ks = decltype(kc)::value;
+          Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
+          step_fence();
+          frag_wait(cur);
+          if constexpr (ks < 7) frag_issue<4096 * (ks + 1)>(nxt, a0);
+          if constexpr (ks < 7)
+            act_kstep<X3>(Hs[2 * ks + 2], Hs[2 * ks + 3], S0, T0, 32 * (ks + 1) + g4, ahi[ks + 1], alo[ks + 1], amax16);
+          acc_cur[0] = mfma16(cur.h0, ahi[ks], acc_cur[0]);
+          acc_cur[1] = mfma16(cur.h1, ahi[ks], acc_cur[1]);
+          if (X3) {
+            acc_cur[0] = mfma16(cur.h0, alo[ks], acc_cur[0]);
+            acc_cur[1] = mfma16(cur.h1, alo[ks], acc_cur[1]);
+            acc_cur[0] = mfma16(cur.l0, ahi[ks], acc_cur[0]);
+            acc_cur[1] = mfma16(cur.l1, ahi[ks], acc_cur[1]);
+          }
+          if constexpr (ks == 0) keep_alive(cur);
+          else keep_alive(cur, prv);
+        });
+      }
+#else
       {
         const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * blk * 8) & 3) * HALF_BYTES) + lane;
         act_kstep<X3>(Hs[0], Hs[1], S0, T0, g4, ahi[0], alo[0], amax16);
@@ -241,6 +372,8 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           }
         }
       }
+#endif
+      step_fence();
       __syncthreads();
 
       for (int mb = 0; mb < 8; ++mb) {
@@ -249,20 +382,78 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
         f32x4 acc_next[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         half8 bhi, blo;
         act_kstep<X3>(acc_cur[0], acc_cur[1], S1, T1, 32 * mb + g4, bhi, blo, amax16);
-        // ---- phase A: fc_0 block mb+1 (two accumulator chains) with this iteration's LDS-DMA
-        // pieces in between
         auto issue_dma = [&](int j) {          // piece j (0..7) of this slab's two halves
 #if DEC8_NODMA
           (void)j;
 #else
           const int h = 2 * c + 3 + (j >> 2);
           if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, j & 3, wave, lane);
-          // scheduling fence: keeps the compiler from interleaving the next LDS reads / the next M0 set-up
-          // with this transfer's issue.  Free (+0.4 %), and the one change that made the static-priority
-          // build's wrong 16-point groups disappear (10/10 -> 0/10; profiles/r02_decoder_ablation.txt section 5)
+#if DEC8_FENCE
+          // round 2's scheduling fence (the one change that made the static-priority build's wrong 16-point
+          // groups disappear then); superseded by the rotating fragment sets, kept for A/B
           asm volatile("s_nop 0" ::: "memory");
 #endif
+#endif
         };
+#if DEC8_ROT
+        // ---- phase A: fc_0 block mb+1 (two accumulator chains) with this iteration's LDS-DMA pieces in
+        // between; phase B: H'[t] += fc_1[16t.., slab mb] a2', sixteen accumulators, two chains at a time.
+        // ONE sequence of 16 k-steps for the fragment rotation: step 7 of phase A prefetches phase B's first set.
+        const half8 *aA = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 2) & 3) * HALF_BYTES) + lane;
+        const half8 *aB = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 1) & 3) * HALF_BYTES) + lane;
+        Frag4 fs[3];
+        if (mb < 7) {
+          frag_issue<0>(fs[0], aA);
+          static_for<0, 8>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
+            step_fence();
+            frag_wait(cur);
+            if constexpr (ks < 7) frag_issue<4096 * (ks + 1)>(nxt, aA);
+            else frag_issue<0>(nxt, aB);
+            issue_dma(ks);
+            acc_next[0] = mfma16(cur.h0, ahi[ks], acc_next[0]);
+            acc_next[1] = mfma16(cur.h1, ahi[ks], acc_next[1]);
+            if (X3) {
+              acc_next[0] = mfma16(cur.h0, alo[ks], acc_next[0]);
+              acc_next[1] = mfma16(cur.h1, alo[ks], acc_next[1]);
+              acc_next[0] = mfma16(cur.l0, ahi[ks], acc_next[0]);
+              acc_next[1] = mfma16(cur.l1, ahi[ks], acc_next[1]);
+            }
+            if constexpr (ks == 0) keep_alive(cur);
+            else keep_alive(cur, prv);
+          });
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) issue_dma(j);
+          frag_issue<0>(fs[8 % 3], aB);
+        }
+        static_for<0, 8>([&](auto kc) {
+          constexpr int tp = decltype(kc)::value;
+          constexpr int ks = 8 + tp;
+          Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
+          step_fence();
+          frag_wait(cur);
+          if constexpr (tp < 7) frag_issue<4096 * (tp + 1)>(nxt, aB);
+          Hs[2 * tp] = mfma16(cur.h0, bhi, Hs[2 * tp]);
+          Hs[2 * tp + 1] = mfma16(cur.h1, bhi, Hs[2 * tp + 1]);
+          if (X3) {
+            Hs[2 * tp] = mfma16(cur.h0, blo, Hs[2 * tp]);
+            Hs[2 * tp + 1] = mfma16(cur.h1, blo, Hs[2 * tp + 1]);
+            Hs[2 * tp] = mfma16(cur.l0, bhi, Hs[2 * tp]);
+            Hs[2 * tp + 1] = mfma16(cur.l1, bhi, Hs[2 * tp + 1]);
+          }
+          // tp == 0: the set before this one is phase A's step 7 (mb < 7) or nothing (mb == 7, behind a barrier)
+          if constexpr (tp == 0) {
+            if (mb < 7) keep_alive(cur, prv);
+            else keep_alive(cur);
+          } else {
+            keep_alive(cur, prv);
+          }
+        });
+#else
+        // ---- phase A: fc_0 block mb+1 (two accumulator chains) with this iteration's LDS-DMA
+        // pieces in between
         auto phase_a = [&]() {
         if (mb < 7) {
           const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 2) & 3) * HALF_BYTES) + lane;
@@ -314,11 +505,14 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
             }
           }
         };
+        phase_a();
+        phase_b();
+#endif
         // (running the two phases in opposite order on the two waves of a SIMD, spreading the DMA
         // pieces over both phases, or letting one wave of a pair issue all of them: all within 0.7 %,
         // the swap -8 % with 28 spilled registers -- profiles/r02_decoder_ablation.txt)
-        phase_a();
-        phase_b();
+        step_fence();       // the slab's last MFMAs stay in front of the barrier (hipcc sinks them behind it otherwise,
+                            // right in front of the next slab's conditioning-table loads into the registers they read)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         acc_cur[0] = acc_next[0];
@@ -391,11 +585,11 @@ static int decode_w8(int n_tiles, const float *pts, const int *tile_prop, const 
   const int grid = ceil_div(n_tiles, tiles_per_wg);
   if (mode == RFD_OCC_MODE_F16X3) {
     hipLaunchKernelGGL(occ_decode8_kernel<3>, dim3(grid), dim3(512), 0, s, n_tiles, pts, tile_prop, tile_src,
-                       (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, ws->status, tiles_per_wg,
+                       (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, rfd_status_word(ws, s), tiles_per_wg,
                        lin, values, pstate, n_per);
   } else if (mode == RFD_OCC_MODE_F16X1) {
     hipLaunchKernelGGL(occ_decode8_kernel<1>, dim3(grid), dim3(512), 0, s, n_tiles, pts, tile_prop, tile_src,
-                       (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, ws->status, tiles_per_wg,
+                       (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, rfd_status_word(ws, s), tiles_per_wg,
                        lin, values, pstate, n_per);
   } else {
     rfd_set_error("rfd_occ_decode_w8: unknown mode", hipErrorInvalidValue);

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(PE_THREADS) void pos_embed_kernel(
     int M, int N, int d, int ldx, int rows_per_group, int rows_per_block,
     const float *__restrict__ x, const float *__restrict__ mask, const float *__restrict__ W,
     int ldw, const float *__restrict__ bias, const float *__restrict__ group,
-    float *__restrict__ out, int ldo, unsigned *status) {
+    float *__restrict__ out, int ldo, float next_scale, unsigned *status) {
   float omax = 0.f;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
@@ -52,9 +52,9 @@ __global__ __launch_bounds__(PE_THREADS) void pos_embed_kernel(
       *reinterpret_cast<pe4 *>(out + (size_t)r * ldo + n) = o;
     }
   }
-  // the consumer is a split-precision GEMM (csrc/gemm_f16x3.hip, activations scaled by 2^4 before
-  // the f16 split): a value beyond 65504 / 16 would be silently saturated there -- say so
-  if (omax * 16.f >= 65504.f) atomicOr(status, 4u);
+  // the consumer is a split-precision GEMM (csrc/gemm_f16x3.hip, activations scaled by 2^sa before
+  // the f16 split): a value beyond 65504 / 2^sa would be silently saturated there -- say so
+  if (omax * next_scale >= 65504.f) atomicOr(status, 4u);
 }
 
 }  // namespace
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(PE_THREADS) void pos_embed_kernel(
 // bias [N], group [M / rows_per_group][N], out [M][ldo]; N % 4 == 0, 16-byte aligned out / bias / group.
 RFD_API int rfd_pos_embed(int M, int N, int d, const float *x, int ldx, const float *mask,
                           const float *W, int ldw, const float *bias, const float *group,
-                          int rows_per_group, float *out, int ldo, void *stream) {
+                          int rows_per_group, float *out, int ldo, int sa, void *stream) {
   if (M <= 0 || N <= 0) return 0;
   if (d < 0 || d > PE_MAX_D || (N & 3) || (ldo & 3) || rows_per_group <= 0 ||
       ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)group & 15)) {
@@ -79,7 +79,7 @@ RFD_API int rfd_pos_embed(int M, int N, int d, const float *x, int ldx, const fl
   const int rows_per_block = 64;
   hipLaunchKernelGGL(pos_embed_kernel, dim3(ceil_div(M, rows_per_block)), dim3(PE_THREADS), 0,
                      (hipStream_t)stream, M, N, d, ldx, rows_per_group, rows_per_block, x, mask, W,
-                     ldw, bias, group, out, ldo, ws->status);
+                     ldw, bias, group, out, ldo, ldexpf(1.f, sa), rfd_status_word(ws, (hipStream_t)stream));
   RFD_CHECK_LAUNCH();
   return 0;
 }

@@ -27,8 +27,9 @@ int rfd_get_workspace(RfdWorkspace **out) {
     RfdWorkspace *w = new RfdWorkspace();
     RFD_CHECK(hipMalloc((void **)&w->fps_slots,
                         sizeof(unsigned long long) * (size_t)FPS_RING * FPS_REGION_GRANULES));
-    RFD_CHECK(hipMalloc((void **)&w->status, 64));
-    RFD_CHECK(hipMemset(w->status, 0, 64));
+    RFD_CHECK(hipMalloc((void **)&w->status, sizeof(unsigned) * RFD_STATUS_SLOTS));
+    RFD_CHECK(hipMemset(w->status, 0, sizeof(unsigned) * RFD_STATUS_SLOTS));
+    for (int i = 0; i < RFD_STATUS_SLOTS; ++i) w->status_owner[i].store(nullptr);
     RFD_CHECK(hipMalloc((void **)&w->zeros, sizeof(float) * RFD_ZEROS_FLOATS));
     RFD_CHECK(hipMemset(w->zeros, 0, sizeof(float) * RFD_ZEROS_FLOATS));
     w->ring_pos.store(0);
@@ -42,26 +43,51 @@ int rfd_get_workspace(RfdWorkspace **out) {
 
 RFD_API const char *rfd_last_error_string(void) { return g_last_error.c_str(); }
 
+unsigned *rfd_status_word(RfdWorkspace *ws, hipStream_t stream) {
+  void *key = (void *)stream;
+  if (!key) return ws->status;                              // the null stream shares slot 0
+  for (int i = 1; i < RFD_STATUS_SLOTS; ++i) {
+    void *cur = ws->status_owner[i].load(std::memory_order_acquire);
+    if (cur == key) return ws->status + i;
+    if (!cur) {
+      void *expected = nullptr;
+      if (ws->status_owner[i].compare_exchange_strong(expected, key, std::memory_order_acq_rel)) return ws->status + i;
+      if (expected == key) return ws->status + i;
+    }
+  }
+  return ws->status;                                        // more than 63 streams: the shared word
+}
+
+// Every word (all streams): synchronises the DEVICE, returns the OR of the flags and clears them.
 RFD_API int rfd_device_status(void) {
   RfdWorkspace *ws;
   if (rfd_get_workspace(&ws)) return -1;
-  unsigned v = 0;
+  unsigned v[RFD_STATUS_SLOTS];
   if (hipDeviceSynchronize() != hipSuccess) return -2;
-  if (hipMemcpy(&v, ws->status, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -3;
-  if (v) (void)hipMemset(ws->status, 0, sizeof(v));
-  return (int)v;
+  if (hipMemcpy(v, ws->status, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  unsigned all = 0;
+  for (int i = 0; i < RFD_STATUS_SLOTS; ++i) all |= v[i];
+  if (all) (void)hipMemset(ws->status, 0, sizeof(v));
+  return (int)all;
 }
 
-// Same word, but waits only for `stream` (several scenes may be in flight on other streams).
+// The word of `stream` only: waits for that stream (several scenes may be in flight on other streams, each with
+// its own word, so a scene neither sees nor clears another scene's flags).  The shared word 0 (null stream, or
+// more streams than slots) is included read-only: it is cleared by rfd_device_status alone.
 RFD_API int rfd_stream_status(void *stream) {
   RfdWorkspace *ws;
   if (rfd_get_workspace(&ws)) return -1;
-  unsigned v = 0;
-  if (hipMemcpyAsync(&v, ws->status, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+  unsigned *word = rfd_status_word(ws, (hipStream_t)stream);
+  unsigned v[2] = {0, 0};
+  if (hipMemcpyAsync(&v[0], word, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+    return -3;
+  if (word != ws->status &&
+      hipMemcpyAsync(&v[1], ws->status, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
     return -3;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -2;
-  if (v) (void)hipMemsetAsync(ws->status, 0, sizeof(v), (hipStream_t)stream);
-  return (int)v;
+  // stream-ordered reset: only kernels of this stream write this word
+  if (v[0]) (void)hipMemsetAsync(word, 0, sizeof(unsigned), (hipStream_t)stream);
+  return (int)(v[0] | v[1]);
 }
 
 RFD_API const char *rfd_build_arch(void) { return "gfx950"; }

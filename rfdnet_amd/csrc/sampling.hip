@@ -328,7 +328,7 @@ int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
     int *ix = idxs + (size_t)b0 * m;
     float *nx = new_xyz ? new_xyz + (size_t)b0 * m * 3 : nullptr;
     switch (ppt) {
-#define FPS_CASE(P) case P: rc = launch_fps<P>(nb, n, m, G, bs_log2, cpb, ds, tp, ix, nx, slots, ws->status, s); break;
+#define FPS_CASE(P) case P: rc = launch_fps<P>(nb, n, m, G, bs_log2, cpb, ds, tp, ix, nx, slots, rfd_status_word(ws, s), s); break;
       FPS_CASE(1) FPS_CASE(2) FPS_CASE(4) FPS_CASE(8) FPS_CASE(10) FPS_CASE(16) FPS_CASE(32) FPS_CASE(64)
 #undef FPS_CASE
       default: rc = (int)hipErrorInvalidValue;

@@ -11,7 +11,8 @@ import torch
 
 from . import _lib, occ_fold
 
-SA = 4            # activations scaled by 2^4 before the f16 split (|a| < 4094)
+SA = 4            # activations scaled by 2^SA before the f16 split (|a| < 4094); lower_scale() -> SA_FALLBACK
+SA_FALLBACK = 1   # after an f16-range flag (status bit 4): |a| < 32752
 _cache = {}
 
 
@@ -67,6 +68,19 @@ def linear(x, weight, bias=None, gbias=None, rows_per_group=1, residual=None, re
             int(pool_signed), _lib.current_stream())
     _lib.check(rc, "rfd_gemm_f16x3")
     return out
+
+
+def lower_scale():
+    """After status bit 4 (a stored activation * 2^SA reached the f16 limit): switch every split-precision GEMM of
+    this process to the fallback scale, once.  True = run the stage again; False = already at the fallback scale."""
+    global SA
+    if SA <= SA_FALLBACK:
+        return False
+    import warnings
+    warnings.warn("split-precision GEMM: an activation exceeded the f16 range at scale 2^%d; re-running at 2^%d "
+                  "(kept from now on)" % (SA, SA_FALLBACK), RuntimeWarning)
+    SA = SA_FALLBACK
+    return True
 
 
 def pool_usable(M, N, K, rows_per_group):

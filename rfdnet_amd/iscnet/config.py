@@ -46,7 +46,9 @@ class ScannetConfig(object):
     (`mean_size_arr=`), then $RFD_MEAN_SIZE_NPZ, then that relative path; if none
     exists a neutral placeholder is used and `placeholder_sizes` is set --
     parse_predictions (box decoding, empty-box removal, 3-D NMS: everything behind
-    `selection='nms'`) warns, because its boxes are then NOT the reference's."""
+    `selection='nms'`) then RAISES like the reference's missing-file error, unless the
+    caller opts in (eval config 'allow_placeholder_sizes'); paths that never decode boxes
+    (`selection='all'`, the benchmark) are unaffected."""
 
     def __init__(self, mean_size_arr=None):
         self.num_class = 8

@@ -134,18 +134,48 @@ class ISCNet(nn.Module):
         ids = self.select_proposals(end_points, selection, pc)
         if ids.shape[1] == 0:                  # nothing survived the selection
             return end_points, ids, []
-        codes = self.object_codes(end_points, proposal_features, ids, pc)
-        cls = self.cls_codes(end_points, ids)
-        gen = self.completion.generator
-        if return_grids:
-            out = gen.generate_grids(codes, cls)
-        else:
-            out = gen.generate_mesh(codes, cls)
-        # FPS exchange time-outs and decoder f16 overflow are reported through a device status
-        # word, not through return codes (the kernels are asynchronous): never hand back results
-        # without reading it.  Waits for THIS stream only (several scenes may be in flight).
-        self.check_device_status(pc.device)
+        out = self.reconstruct(end_points, proposal_features, ids, pc, return_grids=return_grids)
         return end_points, ids, out
+
+    def reconstruct(self, end_points, proposal_features, ids, pc, return_grids=False, hook=None):
+        """skip propagation -> object codes -> occupancy completion for the selected proposals, with the status
+        reads that must follow (see complete()).  A split-precision GEMM activation beyond the f16 range at the
+        default scale (status bit 4, skip-propagation encoder) does not fail the scene either: the stage is run
+        again at the fallback scale (gemm.lower_scale), and only a second flag raises.
+        hook(codes, cls): called before the completion (the benchmark installs its copy scheduling there)."""
+        from .. import _lib, gemm
+        for attempt in (0, 1):
+            codes = self.object_codes(end_points, proposal_features, ids, pc)
+            cls = self.cls_codes(end_points, ids)
+            if hook is not None:
+                hook(codes, cls)
+            try:
+                return self.complete(codes, cls, pc.device, return_grids=return_grids)
+            except _lib.RfdHipError as e:
+                if attempt == 0 and getattr(e, 'status', 0) & 4 and not getattr(e, 'status', 0) & ~4 \
+                        and gemm.lower_scale():
+                    continue
+                raise
+
+    def complete(self, codes, cls, device, return_grids=False, before_meshes=None):
+        """Occupancy completion of the selected proposals + the status read that must follow it.
+        FPS exchange time-outs and f16-range flags are reported through the stream's status word, not through
+        return codes (the kernels are asynchronous): never hand back results without reading it (waits for THIS
+        stream only; several scenes may be in flight, each stream has its own word).  A decoder activation beyond
+        the f16 range at the default scale does not fail the scene: the completion is run again at the fallback
+        scale (the reference's fp32 decoder cannot overflow, occ_decoder.py:110-123) and only a second flag raises."""
+        from .. import _lib
+        gen = self.completion.generator
+        run = gen.generate_grids if return_grids else gen.generate_mesh
+        out = run(codes, cls)
+        with torch.cuda.device(device):
+            st = _lib.stream_status_bits()
+        if st & 2 and self.completion.decoder.lower_activation_scale():
+            out = run(codes, cls)
+            with torch.cuda.device(device):
+                st = (st & ~2) | _lib.stream_status_bits()
+        _lib.raise_status(st)
+        return out
 
     @staticmethod
     def check_device_status(device):

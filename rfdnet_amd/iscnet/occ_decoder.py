@@ -86,6 +86,11 @@ class DecoderCBatchNorm(nn.Module):
         # which kernel: 'w4' = four 496-register waves per workgroup (csrc/occ_decoder.hip),
         # 'w8' = eight waves, two per SIMD (csrc/occ_decoder8.hip); same results
         self.kernel = os.environ.get("RFD_DECODER_KERNEL", "w8")
+        # activation scale 2^ka of the split-f16 arithmetic (occ_fold.py): lowered ONCE, for good, by
+        # lower_activation_scale() when a launch reports an activation beyond the f16 range at the current scale --
+        # the reference's fp32 decoder (occ_decoder.py:110-123) cannot overflow, so neither may this one fail a scene
+        self.ka = occ_fold.KA
+        self.check_range = True        # forward() reads the stream's status word after the launch
         self._packed = None
         self._packed_key = None
 
@@ -130,14 +135,26 @@ class DecoderCBatchNorm(nn.Module):
             if self.z_dim == 0:
                 sd["fc_z.weight"] = torch.zeros(256, 0, device=c.device)
                 sd["fc_z.bias"] = torch.zeros(256, device=c.device)
-            return occ_fold.fold_table(sd, z, c, kw0, kw1)
+            return occ_fold.fold_table(sd, z, c, kw0, kw1, ka=self.ka)
         key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
-            tuple((b.data_ptr(), b._version) for b in self.buffers())
+            tuple((b.data_ptr(), b._version) for b in self.buffers()) + (self.ka,)
         if getattr(self, "_fold_key", None) != key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            self._fold_consts = occ_fold.stacked_constants(sd, kw0, kw1)
+            self._fold_consts = occ_fold.stacked_constants(sd, kw0, kw1, ka=self.ka)
             self._fold_key = key
         return occ_fold.fold_table_stacked(self._fold_consts, z, c)
+
+    def lower_activation_scale(self):
+        """After status bit 2 (an activation * 2^ka reached the f16 limit): switch to the fallback scale, once.
+        Returns True if the caller should run the launch again, False if the fallback scale is already in use
+        (then the overflow is real: |activation| >= 8190)."""
+        if self.ka <= occ_fold.KA_FALLBACK:
+            return False
+        import warnings
+        warnings.warn("occupancy decoder: an activation exceeded the f16 range at scale 2^%d; re-running at 2^%d "
+                      "(kept for this decoder from now on)" % (self.ka, occ_fold.KA_FALLBACK), RuntimeWarning)
+        self.ka = occ_fold.KA_FALLBACK
+        return True
 
     def can_scatter(self):
         """the eight-wave kernel can write MISE's value / known arrays itself (decode_tiles(scatter=...))"""
@@ -196,4 +213,15 @@ class DecoderCBatchNorm(nn.Module):
         tiles_per = tpad // TILE
         tile_prop = torch.arange(B, dtype=torch.int32, device=p.device).repeat_interleave(tiles_per)
         logits = self.decode_tiles(pp.reshape(-1, 3), tile_prop, table, fc_p_w)
+        if self.check_range:
+            # the module's own forward is synchronous about the f16-range flag (one 4-byte read on this stream):
+            # an overflow at the default scale is answered by the fallback scale, not by an exception
+            with torch.cuda.device(p.device):
+                st = _lib.stream_status_bits()
+            if st & 2 and self.lower_activation_scale():
+                table, fc_p_w = self.fold(z.float(), c.float())
+                logits = self.decode_tiles(pp.reshape(-1, 3), tile_prop, table, fc_p_w)
+                with torch.cuda.device(p.device):
+                    st = (st & ~2) | _lib.stream_status_bits()
+            _lib.raise_status(st)
         return logits.view(B, tpad)[:, :T]

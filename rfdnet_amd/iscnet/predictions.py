@@ -10,6 +10,7 @@ scan points per box (:186-197, libs.py:128-137) and a numpy greedy NMS
 and the two heavy parts are HIP kernels (csrc/boxes.hip); nothing leaves the
 device except the final list of proposal ids.
 """
+import os
 import warnings
 
 import numpy as np
@@ -77,9 +78,14 @@ def parse_predictions(end_points, point_clouds, dataset_config, config=None):
     cfg = dict(DEFAULT_EVAL_CONFIG)
     cfg.update(config or {})
     if getattr(dataset_config, 'placeholder_sizes', False):
-        warnings.warn("parse_predictions: mean_size_arr is the PLACEHOLDER (datasets/scannet/scannet_means.npz "
-                      "not found and no mean_size_arr given): decoded boxes, empty-box removal and NMS differ "
-                      "from the reference's", RuntimeWarning, stacklevel=2)
+        # the reference fails hard when datasets/scannet/scannet_means.npz is missing (scannet_config.py:21); so does
+        # this path, unless a synthetic run opts in explicitly
+        msg = ("parse_predictions: mean_size_arr is the PLACEHOLDER (datasets/scannet/scannet_means.npz not found and "
+               "no mean_size_arr given): decoded boxes, empty-box removal and NMS would differ from the reference's")
+        if not (cfg.get('allow_placeholder_sizes') or os.environ.get('RFD_ALLOW_PLACEHOLDER_SIZES') == '1'):
+            raise FileNotFoundError(msg + "; pass mean_size_arr / --mean-size-npz / $RFD_MEAN_SIZE_NPZ, or opt in with "
+                                    "eval config 'allow_placeholder_sizes' (demo.py --allow-placeholder-sizes)")
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
     dev = end_points['center'].device
     center, size, angle = decode_boxes(end_points, dataset_config)
     B, K = angle.shape
@@ -102,9 +108,10 @@ def parse_predictions(end_points, point_clouds, dataset_config, config=None):
         raise NotImplementedError("2-D NMS (use_3d_nms: False) is not used by RfD-Net's configs")
     aabb = torch.cat([corners.min(dim=2)[0], corners.max(dim=2)[0]], -1).contiguous()    # (B,K,6)
     keep = torch.empty(B, K, dtype=torch.uint8, device=dev)
-    # nms.py:90-94: `I = np.argsort(score)`, candidates taken from the END: among equal scores the
-    # HIGHEST index goes first (what an ascending sort that keeps equal keys in index order gives;
-    # numpy's default sort does so for the short runs it finishes by insertion)
+    # nms.py:90-94: `I = np.argsort(score)`, candidates taken from the END.  Among EQUAL scores this takes the highest
+    # index first -- what a stable ascending sort gives.  Best effort only: numpy's default argsort (introsort / SIMD
+    # sort for 256 floats) does not specify the order of ties, so the reference's own tie order is not defined;
+    # exact ties between softmax probabilities of different proposals do not occur in practice.
     order = torch.flip(torch.argsort(obj_prob, dim=1, descending=False, stable=True), dims=[1]).int().contiguous()
     cls_i = pred_sem_cls.int().contiguous()
     valid = nonempty.contiguous()

@@ -25,7 +25,8 @@ import math
 
 import torch
 
-KA = 6               # activation scale 2^6 (csrc/occ_decoder.hip ACT_SCALE)
+KA = 6               # default activation scale 2^6: f16 lo parts stay normal down to |a| ~ 2^-9
+KA_FALLBACK = 3      # scale after an f16-range flag (status bit 2): activations up to 8190 instead of 1023
 BN_EPS = 1e-5
 N_BLOCKS = 5
 HIDDEN = 256
@@ -54,7 +55,7 @@ def cbn_scale_shift(c, conv_gamma_w, conv_gamma_b, conv_beta_w, conv_beta_b,
     return scale, shift
 
 
-def fold_table(sd, z, c, kw0, kw1, prefix=""):
+def fold_table(sd, z, c, kw0, kw1, prefix="", ka=KA):
     """Build the (K,23,256) fp32 table and the scaled fc_p weight.
 
     sd: state_dict-like mapping with the reference's DecoderCBatchNorm key
@@ -64,6 +65,7 @@ def fold_table(sd, z, c, kw0, kw1, prefix=""):
         return sd[prefix + k]
 
     K = c.shape[0]
+    KA = ka
     KH = KA + kw1
     zb = torch.addmm(g("fc_z.bias"), z, g("fc_z.weight").t()) if z.shape[1] > 0 \
         else torch.zeros(K, HIDDEN, device=c.device, dtype=c.dtype)
@@ -93,7 +95,7 @@ def fold_table(sd, z, c, kw0, kw1, prefix=""):
     return table, fc_p_w
 
 
-def stacked_constants(sd, kw0, kw1, prefix=""):
+def stacked_constants(sd, kw0, kw1, prefix="", ka=KA):
     """Everything of fold_table() that does not depend on the codes, stacked over
     the 11 CBN layers (order: blocks.i.bn_0, blocks.i.bn_1 for i<5, then bn) so
     that the per-scene fold is ONE (K,C)x(C,22*256) GEMM and a handful of
@@ -105,6 +107,7 @@ def stacked_constants(sd, kw0, kw1, prefix=""):
     for i in range(N_BLOCKS):
         names += ["blocks.%d.bn_0" % i, "blocks.%d.bn_1" % i]
     names.append("bn")
+    KA = ka
     KH = KA + kw1
     wg = [g(n + ".conv_gamma.weight").reshape(HIDDEN, -1) for n in names]
     wb = [g(n + ".conv_beta.weight").reshape(HIDDEN, -1) for n in names]

@@ -2,7 +2,7 @@
 out[r] = bias + mask[r] * (x[r, :d] @ W[:, :d].T + group[r // rows_per_group])."""
 import torch
 
-from . import _lib
+from . import _lib, gemm
 
 
 def usable(x, W, out):
@@ -21,6 +21,6 @@ def pos_embed(x, mask, W, bias, group, rows_per_group, out):
     with torch.cuda.device(x.device):
         rc = _lib.lib().rfd_pos_embed(M, N, d, x.data_ptr(), x.stride(0), mask.data_ptr(), W.data_ptr(),
                                       W.stride(0), bias.data_ptr(), group.data_ptr(), int(rows_per_group),
-                                      out.data_ptr(), out.stride(0), _lib.current_stream())
+                                      out.data_ptr(), out.stride(0), gemm.SA, _lib.current_stream())
     _lib.check(rc, "rfd_pos_embed")
     return out

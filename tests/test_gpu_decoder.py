@@ -78,13 +78,36 @@ def test_decoder_point_independence(hip):
     np.testing.assert_array_equal(a.cpu().numpy()[0][perm], b.cpu().numpy()[0])
 
 
-def test_decoder_flags_f16_overflow(hip):
-    dec = seeded_decoder(7)
-    with torch.no_grad():
-        dec.blocks[0].bn_0.conv_beta.bias.fill_(5000.0)      # activations ~5000 * 2^6 > f16 max
-        p = torch.zeros(1, 128, 3).cuda()
-        dec(p, torch.zeros(1, 32).cuda(), torch.zeros(1, 512).cuda())
-    with pytest.raises(hip.RfdHipError, match="f16 range"):
+def test_decoder_f16_overflow_falls_back_to_a_smaller_scale(hip, oracle):
+    """The reference's fp32 decoder cannot overflow (occ_decoder.py:110-123).  Here activations are scaled by 2^6
+    before the f16 split: |a| >= 1023.5 raises status bit 2 -- and the module answers with ONE re-run at scale 2^3
+    (|a| < 8190), not with an exception; the logits must still match the oracle.  Only an overflow at the fallback
+    scale raises."""
+    for kern in ("w8", "w4"):
+        dec = seeded_decoder(7)
+        dec.kernel = kern
+        with torch.no_grad():
+            dec.blocks[0].bn_0.conv_beta.bias.fill_(5000.0)      # activations ~5000: * 2^6 > f16 max, * 2^3 fits
+        rng = np.random.default_rng(2)
+        p = ((rng.random((2, 256, 3)) - 0.5) * 1.1).astype(np.float32)
+        z = np.zeros((2, 32), np.float32)
+        c = rng.normal(0, 1, (2, 512)).astype(np.float32)
+        with torch.no_grad(), pytest.warns(RuntimeWarning, match="f16 range"):
+            out = dec(torch.from_numpy(p).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(c).cuda())
+        assert dec.ka == 3
+        hip.device_status()                                       # nothing left flagged
+        sd = OrderedDict((k, v.detach().cpu().numpy()) for k, v in dec.state_dict().items())
+        ref = oracle.decoder_cbn(oracle.decoder_param_blob(sd), p, z, c)
+        err = np.abs(out.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+        print("%s: fallback scale 2^3, max |dlogit| / max(1, |logit|) = %.2e (|logit| up to %.3g)" % (kern, err, np.abs(ref).max()))
+        assert err < 1e-4
+        with torch.no_grad():                                     # the scale stays lowered: no second warning, same result
+            again = dec(torch.from_numpy(p).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(c).cuda())
+        assert torch.equal(out, again)
+        with torch.no_grad():
+            dec.blocks[0].bn_0.conv_beta.bias.fill_(60000.0)     # beyond the fallback scale too: a real error
+            with pytest.raises(hip.RfdHipError, match="f16 range"):
+                dec(torch.from_numpy(p).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(c).cuda())
         hip.device_status()
 
 

@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from rfdnet_amd import synthetic
+
 pytestmark = pytest.mark.gpu
 
 
@@ -191,3 +193,71 @@ def test_gemm_flags_activations_beyond_the_f16_range(hip):
     assert abs(float(y[7, 11]) - 6000.0) < 1e-1   # this product is still right ...
     with pytest.raises(hip.RfdHipError, match="split-precision GEMM"):
         hip.device_status()                        # ... but the next split layer would saturate on it
+
+
+def test_pool_only_launch_is_range_checked_too(hip):
+    """store=False launches feed the pooled maximum to the next split GEMM: the range watch covers them as well
+    (round-2 advisory: `if (g.C && ...)` skipped them)."""
+    from rfdnet_amd import gemm
+    M, N, K, T = 256, 256, 128, 64
+    x = torch.zeros(M, K, device="cuda")
+    x[7, 0] = 100.0
+    w = torch.zeros(N, K, device="cuda")
+    w[11, 0] = 60.0
+    pool = torch.zeros(M // T, N, device="cuda")
+    assert gemm.pool_usable(M, N, K, T)
+    gemm.linear(x, w, rows_per_group=T, pool=pool, store=False)
+    assert abs(float(pool[0, 11]) - 6000.0) < 1e-1
+    with pytest.raises(hip.RfdHipError, match="split-precision GEMM"):
+        hip.device_status()
+
+
+def test_status_words_are_per_stream(hip):
+    """Scenes in flight on different streams must not see or clear each other's flags (round-2 advisory on
+    rfd_stream_status): a flag raised by a launch on stream A is reported to A's status read only."""
+    from rfdnet_amd import _lib, gemm
+    w = torch.randn(128, 32, device="cuda") * 0.1
+    bad = torch.zeros(128, 32, device="cuda")
+    bad[3, 5] = 5000.0
+    good = torch.zeros(128, 32, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        gemm.linear(bad, w)
+    with torch.cuda.stream(sb):
+        gemm.linear(good, w)
+        assert _lib.stream_status_bits() == 0          # B finishes first, sees nothing and clears nothing
+    with torch.cuda.stream(sa):
+        assert _lib.stream_status_bits() == 4          # A's flag is still there
+        assert _lib.stream_status_bits() == 0          # ... and was reset by A's own read
+    hip.device_status()
+
+
+def test_scene_survives_a_gemm_range_flag(hip):
+    """An activation beyond the f16 range at the default GEMM scale (2^4) re-runs the stage at 2^1 instead of failing
+    the scene (the reference's fp32 layers cannot overflow); the codes agree with a run that used the small scale
+    from the start."""
+    from rfdnet_amd import gemm
+    from rfdnet_amd.iscnet.config import Config
+    from rfdnet_amd.iscnet.network import ISCNet
+    cfg = Config({'generation': {'resolution_0': 8, 'upsampling_steps': 0}})
+    net = ISCNet(cfg)
+    synthetic.load_seeded(net, 10)
+    net = net.cuda().eval()
+    enc = net.skip_propagation.encoder
+    with torch.no_grad():
+        enc.fc_pos.bias[:8] = 5000.0                    # 5000 * 2^4 > 65504 > 5000 * 2^1
+    pc = torch.from_numpy(synthetic.synthetic_scene(seed=3, n_raw=9000, n_points=8192)[None]).cuda()
+    assert gemm.SA == 4
+    try:
+        with torch.no_grad():
+            ep, pf = net.detect(pc)
+            ids = net.select_proposals(ep, 'all', pc)[:, :8].contiguous()
+            with pytest.warns(RuntimeWarning, match="f16 range"):
+                grids = net.reconstruct(ep, pf, ids, pc, return_grids=True)
+            assert gemm.SA == gemm.SA_FALLBACK
+            again = net.reconstruct(ep, pf, ids, pc, return_grids=True)     # no flag, no warning, same result
+        assert torch.equal(grids, again) and torch.isfinite(grids).all()
+        hip.device_status()
+    finally:
+        gemm.SA = 4
