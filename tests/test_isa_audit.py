@@ -32,3 +32,36 @@ def test_row_owner_gemm_has_no_use_before_landed(tmp_path):
         seen, problems = audit_vmcnt.audit(asm, "gemm_rows8_kernel" + variant)
         assert seen['loads'] >= 40 and seen['waits'] >= 8, seen      # the audit saw the hand-issued loads
         assert problems == [], problems[:5]
+
+
+def _asm(tmp_path, src, name, extra=()):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    asm = str(tmp_path / name)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "rfdnet_amd", "csrc"),
+                    "-S", "--cuda-device-only", "-o", asm, os.path.join(ROOT, "rfdnet_amd", "csrc", src)] + list(extra),
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path))
+    return asm
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
+                    reason="hipcc not available")
+def test_decoder8_prefetch_never_lands_on_recently_read_mfma_sources(tmp_path):
+    """The eight-wave decoder's weight-fragment prefetch (and every other LDS / global load in the kernel) must
+    not write a register that one of the last SIX MFMAs read as SrcA / SrcB, nor one read as SrcC fewer than four
+    wait states earlier (tools/audit_mfma_war.py on the shipped build's assembly; the round-2 build, whose prefetch
+    reused the registers of the MFMAs issued just before, is the control: the audit must flag it).  No spills."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_mfma_war
+    asm = _asm(tmp_path, "occ_decoder8.hip", "dec8.s")
+    text = open(asm).read()
+    assert ".vgpr_spill_count: 0" in text and ".vgpr_spill_count: 1" not in text
+    # "one whole k-step": six MFMAs in the three-term parity mode, two in the single-term throughput mode
+    for inst, step in (("occ_decode8_kernelILi3E", 6), ("occ_decode8_kernelILi1E", 2)):
+        st, problems = audit_mfma_war.audit(asm, inst, min_mfma_gap=step, min_c_states=4)
+        assert st['mfma'] >= 64 and st['loads'] >= 200, st
+        assert problems == [], problems[:5]
+        assert st['min_ab_gap'] is None or st['min_ab_gap'] >= step, st
+    old = _asm(tmp_path, "occ_decoder8.hip", "dec8_r0.s", ("-DDEC8_ROT=0", "-DDEC8_FENCE=1"))
+    st, problems = audit_mfma_war.audit(old, "occ_decode8_kernelILi3E", min_mfma_gap=6, min_c_states=4)
+    assert st['min_ab_gap'] == 0 and len(problems) > 50, (st, len(problems))

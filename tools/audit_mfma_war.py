@@ -10,8 +10,8 @@ states.  Rules (profiles/r03_decoder_hazard.txt):
        (the distance hipcc's own hazard recognizer keeps; inline-asm loads are not padded by hipcc, so this is the
        check that an asm-issued ds_read did not land on a just-read accumulator).
 An s_barrier resets the history (the partner wave has to arrive too, so nothing of the previous phase is still queued).
-Linear scan in program order; at every backward branch the target block is re-scanned once with the history at the
-branch (loop-carried distances).
+Basic-block data flow over the kernel's control-flow graph (per MFMA the smallest distance over all paths, to a fixed
+point), so loop-carried and branch-joined distances are covered.
 usage: audit_mfma_war.py file.s kernel_symbol_substring [min_mfma_gap=6] [min_c_states=6]"""
 import re
 import sys
@@ -53,69 +53,115 @@ def parse(body):
 
 
 def audit(path, sym, min_mfma_gap=6, min_c_states=6):
+    """-> (stats, problems).  Basic-block data flow: the state at a block's entry is the union of its predecessors'
+    exit states (per MFMA the smallest distance over all paths), iterated to a fixed point."""
     start, body = kernel_body(path, sym)
     ins, labels = parse(body)
-    problems, stats = [], {'mfma': 0, 'loads': 0, 'min_ab_gap': None, 'min_c_states': None}
+    n = len(ins)
+    horizon = max(min_mfma_gap, 8)
+    # ---- basic blocks
+    leaders = {0} | set(labels.values())
+    for k, (_, mn, ops) in enumerate(ins):
+        if mn.startswith(('s_cbranch', 's_branch', 's_endpgm', 's_setpc')) and k + 1 < n:
+            leaders.add(k + 1)
+    starts = sorted(x for x in leaders if x < n)
+    block_of = {}
+    blocks = []
+    for bi, st in enumerate(starts):
+        en = starts[bi + 1] if bi + 1 < len(starts) else n
+        blocks.append((st, en))
+        block_of[st] = bi
+    succ = []
+    for (st, en) in blocks:
+        _, mn, ops = ins[en - 1]
+        out = []
+        if mn.startswith(('s_cbranch', 's_branch')):
+            tgt = ops.strip()
+            if tgt in labels and labels[tgt] in block_of:
+                out.append(block_of[labels[tgt]])
+        if not mn.startswith(('s_branch', 's_endpgm', 's_setpc')) and en in block_of:
+            out.append(block_of[en])
+        succ.append(out)
 
-    def scan(lo, hi, hist, count):
-        # hist: list of dicts {line, a, b, c, states_since, mfmas_since}, most recent last
-        for k in range(lo, hi):
+    problems, stats = {}, {'mfma': 0, 'loads': 0, 'min_ab_gap': None, 'min_c_states': None}
+
+    def transfer(bi, state, final):
+        """state: {mfma line: [a, b, c, states, mfmas]} -> exit state"""
+        hist = {k: list(v) for k, v in state.items()}
+        st, en = blocks[bi]
+        for k in range(st, en):
             li, mn, ops = ins[k]
             states = 1
             if mn == 's_barrier':
                 # every wave of the workgroup (the SIMD partner included) has drained its phase: the MFMAs before a
                 # barrier that follows an s_waitcnt on the weight stream are hundreds of cycles old when it releases
-                hist[:] = []
+                hist = {}
                 continue
             if mn == 's_nop':
                 states = int(ops.strip() or 0) + 1
             if mn.startswith(LOADS) and not mn.endswith('lds') and ' lds' not in ops:
                 dst = set(regs(ops.split(',')[0]))
-                if count:
+                if final:
                     stats['loads'] += 1
-                for h in hist:
-                    for kind in ('a', 'b', 'c'):
-                        if dst & h[kind]:
-                            if kind == 'c':
-                                if stats['min_c_states'] is None or h['states'] < stats['min_c_states']:
-                                    stats['min_c_states'] = h['states']
-                                if h['states'] < min_c_states:
-                                    problems.append((start + li + 1, mn + ' ' + ops, start + h['line'] + 1, 'SrcC',
-                                                     h['mfmas'], h['states']))
-                            else:
-                                if stats['min_ab_gap'] is None or h['mfmas'] < stats['min_ab_gap']:
-                                    stats['min_ab_gap'] = h['mfmas']
-                                if h['mfmas'] < min_mfma_gap:
-                                    problems.append((start + li + 1, mn + ' ' + ops, start + h['line'] + 1,
-                                                     'Src' + kind.upper(), h['mfmas'], h['states']))
-            for h in hist:
-                h['states'] += states
+                for ml, h in hist.items():
+                    for kind, regset in (('a', h[0]), ('b', h[1]), ('c', h[2])):
+                        if not (dst & regset):
+                            continue
+                        if kind == 'c':
+                            if stats['min_c_states'] is None or h[3] < stats['min_c_states']:
+                                stats['min_c_states'] = h[3]
+                            if h[3] < min_c_states:
+                                problems[(li, ml, 'SrcC')] = (start + li + 1, mn + ' ' + ops, start + ml + 1, 'SrcC', h[4], h[3])
+                        else:
+                            if stats['min_ab_gap'] is None or h[4] < stats['min_ab_gap']:
+                                stats['min_ab_gap'] = h[4]
+                            if h[4] < min_mfma_gap:
+                                problems[(li, ml, kind)] = (start + li + 1, mn + ' ' + ops, start + ml + 1,
+                                                            'Src' + kind.upper(), h[4], h[3])
+            for h in hist.values():
+                h[3] += states
             if mn.startswith('v_mfma') or mn.startswith('v_smfma'):
                 o = [x.strip() for x in ops.split(',')]
-                if count:
+                if final:
                     stats['mfma'] += 1
-                for h in hist:
-                    h['mfmas'] += 1
-                hist.append({'line': li, 'a': set(regs(o[1])), 'b': set(regs(o[2])),
-                             'c': set(regs(o[3])) if len(o) > 3 else set(), 'states': 0, 'mfmas': 0})
-                # far enough back on both scales: forget
-                hist[:] = [h for h in hist if h['mfmas'] <= max(min_mfma_gap, 8) and h['states'] <= 64 or h['mfmas'] < min_mfma_gap]
-            m = re.match(r'^s_cbranch\S*|^s_branch', mn)
-            if m and count:
-                tgt = ops.strip()
-                if tgt in labels and labels[tgt] <= k:
-                    # loop back edge: re-scan the head of the loop with the history here
-                    scan(labels[tgt], min(labels[tgt] + 400, k), [dict(h) for h in hist], False)
+                for h in hist.values():
+                    h[4] += 1
+                hist[li] = [frozenset(regs(o[1])), frozenset(regs(o[2])),
+                            frozenset(regs(o[3])) if len(o) > 3 else frozenset(), 0, 0]
+                hist = {ml: h for ml, h in hist.items() if h[4] <= horizon and (h[3] <= 64 or h[4] < min_mfma_gap)}
         return hist
 
-    scan(0, len(ins), [], True)
-    # de-duplicate (the back-edge re-scan can repeat findings)
-    seen, uniq = set(), []
-    for p in problems:
-        if p[:4] not in seen:
-            seen.add(p[:4])
-            uniq.append(p)
-    return stats, uniq
+    def merge(dst, src):
+        changed = False
+        for ml, h in src.items():
+            d = dst.get(ml)
+            if d is None:
+                dst[ml] = list(h)
+                changed = True
+            else:
+                if h[3] < d[3]:
+                    d[3] = h[3]
+                    changed = True
+                if h[4] < d[4]:
+                    d[4] = h[4]
+                    changed = True
+        return changed
+
+    entry = [dict() for _ in blocks]
+    work = list(range(len(blocks)))
+    rounds = 0
+    while work and rounds < 50 * len(blocks):
+        rounds += 1
+        bi = work.pop(0)
+        out = transfer(bi, entry[bi], False)
+        for sj in succ[bi]:
+            if merge(entry[sj], out) and sj not in work:
+                work.append(sj)
+    problems.clear()
+    stats.update({'mfma': 0, 'loads': 0, 'min_ab_gap': None, 'min_c_states': None})
+    for bi in range(len(blocks)):
+        transfer(bi, entry[bi], True)
+    return stats, sorted(problems.values())
 
 
 if __name__ == '__main__':
