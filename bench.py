@@ -64,6 +64,10 @@ def parse(argv=None):
     ap.add_argument("--resolution0", type=int, default=None)
     ap.add_argument("--upsampling-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stats-out", type=str, default=None,
+                    help="write per-scene statistics (stage ms from HIP events on the scene's stream, query points, "
+                         "vertices, triangles, failed) of the timed region as JSON to this path (rank r > 0: "
+                         "<path>.rank<r>); the reference prints per-scene time only (demo.py:408-411)")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the one-scene-at-a-time pass after the timed region")
     ap.add_argument("--in-flight", type=int, default=3,
@@ -193,6 +197,7 @@ class HipBackend(object):
         self.args, self.torch, self._lib = args, torch, _lib
         self.S = max(1, args.in_flight)
         self.NB = max(1, args.batch)
+        self.record_scenes, self.scene_records = False, []
         self.nets = [self._build_net() for _ in range(self.S)]
         self.timers = [DecodeTimer(n.completion.decoder) for n in self.nets]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.S)]
@@ -241,8 +246,13 @@ class HipBackend(object):
         torch = self.torch
         net, sink = self.nets[w], self.sinks[w]
         pc = torch.stack([self.scenes[i % self.pool] for i in ids])
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.record_scenes else None
+        if ev:
+            ev[0].record()
         with torch.no_grad():
             end_points, proposal_features = net.detect(pc)
+            if ev:
+                ev[1].record()
             sel = net.select_proposals(end_points, 'all', pc)
             gen = net.completion.generator
             # the previous scene's PCIe copy rides behind the first (longest) decode launch
@@ -250,12 +260,32 @@ class HipBackend(object):
             # skip propagation -> codes -> completion + the stream's status word (FPS time-out -> raises; an
             # f16-range flag -> one re-run of the stage at the fallback activation scale, raises only if that
             # overflows too)
-            meshes = net.reconstruct(end_points, proposal_features, sel, pc)
+            meshes = net.reconstruct(end_points, proposal_features, sel, pc,
+                                     hook=(lambda codes, cls: ev[2].record()) if ev else None)
             if self.args.upsampling_steps == 0:
                 sink.start_pending()
         v, f, _, _ = gen.last_buffers                              # all K meshes: one vertex / one face buffer
         sink.push(v, f)
+        if ev:
+            ev[3].record()
+            self.scene_records.append({"scenes": [int(i) for i in ids], "worker": w, "events": ev,
+                                       "queries": int(gen.stats.get('n_queries', 0)), "rounds": int(gen.stats.get('rounds', 0)),
+                                       "meshes": len(meshes), "vertices": int(v.shape[0]), "triangles": int(f.shape[0]),
+                                       "failed": False})
         return len(meshes), int(v.shape[0]), int(f.shape[0]), gen.stats.get('n_queries', 0)
+
+    def scene_stats(self):
+        """per-scene records of the timed region with the event times resolved (call after the final sync)"""
+        out = []
+        for r in self.scene_records:
+            if r.get("failed"):
+                out.append(r)
+                continue
+            e = r.pop("events")
+            r["ms"] = {"backbone_voting_proposal": e[0].elapsed_time(e[1]), "skip_propagation": e[1].elapsed_time(e[2]),
+                       "completion_mise_decoder_marching_cubes": e[2].elapsed_time(e[3]), "total": e[0].elapsed_time(e[3])}
+            out.append(r)
+        return out
 
     def decode_totals(self):
         tot = [0.0, 0, 0]
@@ -269,6 +299,9 @@ class HipBackend(object):
             tm.enabled = on
             if on:
                 tm.records = []
+        self.record_scenes = bool(on and getattr(self.args, "stats_out", None))
+        if on:
+            self.scene_records = []
 
     def final_check(self):
         self._lib.device_status()
@@ -415,6 +448,8 @@ class StubBackend(object):
         self.args, self.S, self.NB, self.world = args, max(1, args.in_flight), max(1, args.batch), world
         self.fail = {int(x) for x in os.environ.get("RFD_BENCH_STUB_FAIL", "").split(",") if x}
         self.seen = []
+        self.record_scenes, self.scene_records = bool(getattr(args, "stats_out", None)), []
+        self.slow = float(os.environ.get("RFD_BENCH_STUB_SLOW_RANK", "-1")) == rank
 
     def sync(self):
         pass
@@ -426,17 +461,24 @@ class StubBackend(object):
         pass
 
     def run_pass(self, w, ids):
-        time.sleep(0.002)
+        time.sleep(0.02 if self.slow else 0.002)
         self.seen += list(ids)
         if self.fail & set(ids):
             raise RuntimeError("stub scene %s failed" % sorted(self.fail & set(ids)))
+        if self.record_scenes:
+            self.scene_records.append({"scenes": [int(i) for i in ids], "worker": w, "failed": False,
+                                       "queries": sum(100 + i for i in ids), "ms": {"total": 2.0}})
         return 256 * len(ids), 1000 * len(ids), 2000 * len(ids), sum(100 + i for i in ids)
+
+    def scene_stats(self):
+        return list(self.scene_records)
 
     def decode_totals(self):
         return [1.0, 128, 1]
 
     def set_timing(self, on):
-        pass
+        if on:
+            self.scene_records = []
 
     def final_check(self):
         pass
@@ -468,6 +510,9 @@ def run_job(args, be, rank, world, dist):
                     tot = [a + b for a, b in zip(tot, r)]
                 except Exception as e:                    # scene marked failed, the sweep goes on
                     failed += len(ids)
+                    if getattr(be, "record_scenes", False):
+                        be.scene_records.append({"scenes": [int(i) for i in ids], "worker": w, "failed": True,
+                                                 "error": "%s: %s" % (type(e).__name__, e)})
                     sys.stderr.write("[rank %d] scene(s) %s failed: %s: %s\n" % (rank, ids, type(e).__name__, e))
         finally:
             be.worker_end(w, ctx)
@@ -490,6 +535,11 @@ def run_job(args, be, rank, world, dist):
     be.sync()
     elapsed = time.perf_counter() - t0
     dec_ms, dec_pts, dec_launches = be.decode_totals()
+    if getattr(args, "stats_out", None) and hasattr(be, "scene_stats"):
+        path = args.stats_out if rank == 0 else "%s.rank%d" % (args.stats_out, rank)
+        with open(path, "w") as fh:
+            json.dump({"rank": rank, "world": world, "config": args.config, "timed_region_s": elapsed,
+                       "scenes": be.scene_stats()}, fh, indent=1)
     be.set_timing(False)
     be.final_check()
     n_meshes, nv, nt, nq = (sum(r[0][i] for r in res) for i in range(4))

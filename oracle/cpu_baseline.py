@@ -250,12 +250,38 @@ def run(points=80000, resolution0=32, upsampling_steps=1, n_queries_per_scene=No
             return time.perf_counter() - t0
         dec_time(4096)
         t_cal = max(dec_time(16384), 1e-4)
-        n_s = int(min(2 << 20, max(16384, 16384 * (0.4 * budget_s) / t_cal)))
+        n_s = int(min(2 << 20, max(16384, 16384 * (0.2 * budget_s) / t_cal)))
         t_dec = dec_time(n_s)
     if n_queries_per_scene is None:
         n_queries_per_scene = n_prop * (resolution0 + 1) ** 3
-    t['decoder'] = t_dec * n_queries_per_scene / n_s
-    sample['decoder'] = "%d of %d query points (%.1f s measured)" % (n_s, n_queries_per_scene, t_dec)
+    # the same decoder as the OpenMP C restatement (oracle_decoder_cbn: fp32, all cores, one proposal per call in
+    # <=100 000-point batches like generator.py:129-141) -- BOTH legs are reported, the faster one counts
+    from rfdnet_amd.iscnet.occ_decoder import DecoderCBatchNorm
+    dmod = DecoderCBatchNorm(dim=3, z_dim=32, c_dim=512, hidden_size=256)
+    synthetic.load_seeded(dmod, 3)
+    blob = oracle.decoder_param_blob({k: v.numpy() for k, v in dmod.state_dict().items()})
+    zc, cc = np.zeros((1, 32), np.float32), np.random.default_rng(1).normal(0, 1, (1, 512)).astype(np.float32)
+
+    def cdec_time(n):
+        p = ((np.random.default_rng(2).random((1, n, 3)) - 0.5) * 1.1).astype(np.float32)
+        t0 = time.perf_counter()
+        left = 0
+        while left < n:
+            m = min(n - left, 100000)
+            oracle.decoder_cbn(blob, p[:, left:left + m], zc, cc)
+            left += m
+        return time.perf_counter() - t0
+    cdec_time(4096)
+    tc_cal = max(cdec_time(16384), 1e-4)
+    n_c = int(min(4 << 20, max(16384, 16384 * (0.2 * budget_s) / tc_cal)))
+    t_cdec = cdec_time(n_c)
+    legs = {'decoder_torch_module': t_dec * n_queries_per_scene / n_s,
+            'decoder_c_oracle_openmp': t_cdec * n_queries_per_scene / n_c}
+    best = min(legs, key=legs.get)
+    t['decoder'] = legs[best]
+    sample['decoder'] = ("%s leg (torch module: %d points in %.1f s = %.0f points/s; OpenMP C restatement: %d points in "
+                         "%.1f s = %.0f points/s), of %d query points"
+                         % (best, n_s, t_dec, n_s / t_dec, n_c, t_cdec, n_c / t_cdec, n_queries_per_scene))
 
     # ---- MISE octree + marching cubes: C oracle on a sample of proposals --------------------
     n_m = 4
@@ -292,6 +318,7 @@ def run(points=80000, resolution0=32, upsampling_steps=1, n_queries_per_scene=No
                        % (cores, sample['skip_propagation_nets'], sample['decoder'],
                           sample.get('mise_octree', 'n/a (dense grid)'), sample['marching_cubes'])),
             "stage_s": {k: round(v, 4) for k, v in t.items()},
+            "decoder_legs_s": {k: round(v, 3) for k, v in legs.items()},
             "one_core_s": {k: round(v, 3) for k, v in one.items()},
             "scene_s": round(total, 3)}
 

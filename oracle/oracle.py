@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# RFD_ORACLE_LIB: another build of the same source (the sanitizer build, tests/test_oracle_sanitized.py)
+_LIB_PATH = os.environ.get("RFD_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 _lib = None
 
 _f32p = C.POINTER(C.c_float)
@@ -29,7 +30,7 @@ def build(force=False):
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
+    subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_LIB_PATH)],
                           stdout=subprocess.DEVNULL)
     return _LIB_PATH
 

@@ -35,21 +35,67 @@ def free_port():
     return p
 
 
+def _cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def numa_cpus_for_gpu(index, sys_root="/sys"):
+    """Host CPUs of the NUMA node GPU `index` hangs off (KFD topology: the index-th node with SIMDs -> PCI
+    domain / location id -> /sys/bus/pci/devices/<bdf>/numa_node -> node<N>/cpulist).  None when the topology cannot
+    be read or the GPU reports no node (-1): the caller then leaves the affinity alone."""
+    try:
+        base = os.path.join(sys_root, "class", "kfd", "kfd", "topology", "nodes")
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = {}
+            with open(os.path.join(base, n, "properties")) as fh:
+                for line in fh:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        p = gpus[index]
+        loc, dom = int(p["location_id"]), int(p.get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        with open(os.path.join(sys_root, "bus", "pci", "devices", bdf, "numa_node")) as fh:
+            node = int(fh.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sys_root, "devices", "system", "node", "node%d" % node, "cpulist")) as fh:
+            cpus = _cpulist(fh.read())
+        return cpus or None
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 def launch_local_ranks(script, argv, nproc, env=None, timeout=None):
     """One process per GPU of THIS node: re-executes `script argv` nproc times with the
     environment torch.distributed.run would set (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR=127.0.0.1 / MASTER_PORT), rank 0 inheriting stdout.  Returns the worst exit
-    code; if a rank fails the others are terminated (no orphan holding a GPU)."""
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT), rank 0 inheriting stdout, each rank's host threads
+    pinned to the CPUs of its GPU's NUMA node when the topology says which (RFD_PIN_NUMA=0
+    disables it).  Returns the worst exit code; if a rank fails the others are terminated (no
+    orphan holding a GPU)."""
     base = dict(os.environ)
     base.update(env or {})
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(nproc),
                 LOCAL_WORLD_SIZE=str(nproc))
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes)
     procs = []
+    pin = base.get("RFD_PIN_NUMA", "1") != "0" and hasattr(os, "sched_setaffinity")
     for r in range(nproc):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # host threads of rank r (its three scene workers, the pinned-memory copies) stay on the NUMA node of GPU r:
+        # the mesh D2H copies and kernel launches do not cross the socket interconnect
+        cpus = numa_cpus_for_gpu(r) if pin else None
+        pre = (lambda c=cpus: os.sched_setaffinity(0, c)) if cpus else None
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                                      stdout=None if r == 0 else subprocess.DEVNULL, preexec_fn=pre))
     import time
     t_end = None if timeout is None else time.time() + timeout
     rc = 0

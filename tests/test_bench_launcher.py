@@ -75,3 +75,64 @@ def test_failing_rank_takes_the_job_down(tmp_path):
                       "time.sleep(60)\n")
     rc = sharding.launch_local_ranks(str(script), [], 2)
     assert rc == 3
+
+
+def test_eight_ranks_over_gloo_dry_run(tmp_path):
+    """configs[3] / [4] shape without the node: 8 ranks (stub scenes, gloo), one scene in flight per rank;
+    every rank's scenes are its residue class, the job's throughput is paced by the slowest rank, the per-scene
+    statistics file of every rank is written."""
+    stats = str(tmp_path / "scenes.json")
+    p = run_bench(["--gpus", "8", "--steps", "5", "--warmup", "1", "--in-flight", "1", "--stats-out", stats],
+                  RFD_BENCH_STUB_SLOW_RANK="5")
+    assert p.returncode == 0, p.stderr
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["config"]["scenes_per_step"] == 8 and out["config"]["scenes_done"] == 40
+    # rank 5 sleeps 10x longer per scene: 5 scenes x 20 ms is the floor of the job's time
+    assert out["ms_per_step"] >= 19.0, out["ms_per_step"]
+    for r in range(8):
+        d = json.load(open(stats if r == 0 else "%s.rank%d" % (stats, r)))
+        ids = sorted(i for s in d["scenes"] for i in s["scenes"])
+        assert ids == list(range(8 + r, 48, 8)), (r, ids)            # warm-up step = scenes 0..7
+
+
+def test_scene_to_rank_map_of_the_scannet_test_split():
+    """datasets/splits/fullscan/scannetv2_test.json holds 311 scans; scene i -> rank i mod 8."""
+    from rfdnet_amd import sharding
+    n, world = 311, 8
+    parts = [sharding.scene_ids_for_rank(n, r, world) for r in range(world)]
+    assert sorted(i for p in parts for i in p) == list(range(n))
+    assert [len(p) for p in parts] == [39, 39, 39, 39, 39, 39, 39, 38]
+    assert all(i % world == r for r, p in enumerate(parts) for i in p)
+
+
+def test_job_throughput_is_paced_by_the_slowest_rank():
+    import numpy as np
+    from rfdnet_amd import sharding
+    F = sharding.STAT_FIELDS
+    g = np.zeros((8, len(F)))
+    g[:, F.index("steps")] = 39
+    g[:, F.index("elapsed_s")] = [2.0, 2.1, 1.9, 2.0, 2.0, 3.0, 2.0, 2.0]
+    v, t = sharding.job_throughput(g)
+    assert t == 3.0 and abs(v - 8 * 39 / 3.0) < 1e-12
+
+
+def test_numa_cpu_list_from_a_fake_topology(tmp_path):
+    """launch_local_ranks pins rank r to the CPUs of GPU r's NUMA node (KFD topology -> PCI -> node cpulist)."""
+    from rfdnet_amd import sharding
+    root = tmp_path
+    for i, props in enumerate(("simd_count 0\n", "simd_count 1024\nlocation_id 1280\ndomain 0\n",
+                               "simd_count 1024\nlocation_id 34304\ndomain 0\n")):
+        d = root / "class" / "kfd" / "kfd" / "topology" / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(props)
+    for bdf, node in (("0000:05:00.0", "0"), ("0000:86:00.0", "1")):
+        d = root / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(node + "\n")
+    for node, cl in (("node0", "0-3,16-19"), ("node1", "4-7")):
+        d = root / "devices" / "system" / "node" / node
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+    assert sharding.numa_cpus_for_gpu(0, str(root)) == [0, 1, 2, 3, 16, 17, 18, 19]
+    assert sharding.numa_cpus_for_gpu(1, str(root)) == [4, 5, 6, 7]
+    assert sharding.numa_cpus_for_gpu(2, str(root)) is None            # no such GPU: leave the affinity alone
