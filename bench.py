@@ -378,7 +378,8 @@ class HipBackend(object):
                 "min_iou": min(r["iou"] for r in rows), "flips": sum(r["flips"] for r in rows),
                 "max_abs_dlogit": max(r["max_abs_dlogit"] for r in rows),
                 "faces_equal": all(r["faces_hip"] == r["faces_cpu"] for r in rows),
-                "max_vertex_hausdorff_cells": max(r["hausdorff_cells"] for r in rows), "per_proposal": rows}
+                "max_vertex_hausdorff_cells": max(r["hausdorff_cells"] for r in rows),
+                "max_iso_residual_logit": max(r["iso_residual_logit"] for r in rows), "per_proposal": rows}
 
 
 class StressBackend(HipBackend):

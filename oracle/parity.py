@@ -46,6 +46,31 @@ def vertex_hausdorff(v1, v2):
     return float(max(d12, d21))
 
 
+def iso_residual(vertices, grid, threshold_logit, padding=0.1):
+    """How far off the OTHER path's iso-surface do these mesh vertices lie, in logit units: every marching-cubes vertex
+    sits on a grid edge, so the value grid interpolated along that edge at the vertex should equal the threshold.
+    vertices: extract_mesh output coordinates (generator.py:163-168: box * ((v_mc - 1.5) / (n - 1) - 0.5) in the
+    padded grid's index space); vertices on edges that touch the -1e6 padding shell are skipped.
+    -> (max |interpolated value - threshold|, vertices checked)."""
+    n = grid.shape[0]
+    g = (np.asarray(vertices, np.float64) / (1 + padding) + 0.5) * (n - 1) + 0.5      # unpadded grid index coordinates
+    r = np.rint(g)
+    axis = np.argmax(np.abs(g - r), axis=1)                                           # the one fractional coordinate
+    rows = np.arange(len(g))
+    lo = r.astype(np.int64)
+    lo[rows, axis] = np.floor(g[rows, axis]).astype(np.int64)
+    t = g[rows, axis] - lo[rows, axis]
+    hi = lo.copy()
+    hi[rows, axis] += 1
+    hi[rows, axis] = np.where(t == 0.0, lo[rows, axis], hi[rows, axis])               # a vertex exactly on a lattice point
+    ok = (lo >= 0).all(1) & (hi <= n - 1).all(1)
+    lo, hi, t = lo[ok], hi[ok], t[ok]
+    a = grid[lo[:, 0], lo[:, 1], lo[:, 2]]
+    b = grid[hi[:, 0], hi[:, 1], hi[:, 2]]
+    val = a + t * (b - a)
+    return (float(np.abs(val - threshold_logit).max()) if len(val) else 0.0), int(ok.sum())
+
+
 def compare(hip_grid, hip_vertices, hip_faces, cpu_grid, threshold_logit, padding=0.1, near=1e-4):
     """-> dict of the parity figures for one proposal.  Vertex distances are in CELLS of the value grid."""
     hip_grid = np.asarray(hip_grid, np.float64)
@@ -53,7 +78,8 @@ def compare(hip_grid, hip_vertices, hip_faces, cpu_grid, threshold_logit, paddin
     n_near = int((np.abs(cpu_grid - threshold_logit) < near).sum())
     cv, cf = oracle.extract_mesh(cpu_grid, threshold_logit, padding)
     cell = (1 + padding) / (hip_grid.shape[0] - 1)
-    return {"iou": iou, "flips": flips, "near_threshold": n_near,
+    res, n_res = iso_residual(hip_vertices, np.asarray(cpu_grid, np.float64), threshold_logit, padding)
+    return {"iso_residual_logit": res, "iso_vertices_checked": n_res, "iou": iou, "flips": flips, "near_threshold": n_near,
             "max_abs_dlogit": float(np.abs(hip_grid - cpu_grid).max()),
             "points_off_1e-4": int((np.abs(hip_grid - cpu_grid) > 1e-4).sum()),
             "faces_hip": int(len(hip_faces)), "faces_cpu": int(len(cf)),

@@ -304,6 +304,8 @@ __device__ __forceinline__ float dpp_max(float v) {
 __device__ __forceinline__ void pool_finish(const Args &g, float v, size_t grp, int c) {
   float o = __builtin_fmaf(v, g.out_scale, g.bias[c] + g.gbias[grp * g.gbias_stride + c]);
   if (g.relu_out) o = o > 0.f ? o : 0.f;
+  // the pooled value is the next split GEMM's input: same range watch as the stored outputs
+  if (__builtin_fabsf(o) * g.a_scale >= 65504.f) atomicOr(g.status, 4u);
   int *p = reinterpret_cast<int *>(g.pool + grp * g.N + c);
   if (o > 0.f) atomicMax(p, __float_as_int(o));
   else if (g.pool_signed) {

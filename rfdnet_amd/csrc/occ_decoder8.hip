@@ -43,6 +43,12 @@
 #ifndef DEC8_SB
 #define DEC8_SB 1
 #endif
+//   DEC8_PIPE  1 = the CBN + ReLU + split of fc_0's block mb+1 (the B operand of the NEXT slab's fc_1 MFMAs) is cut into
+//                  four slices issued inside steps 1-4 of this slab's phase B, under its MFMAs, instead of standing
+//                  in front of the next slab with the matrix pipe idle (both waves of a SIMD convert at the same time)
+#ifndef DEC8_PIPE
+#define DEC8_PIPE 1
+#endif
 #ifndef DEC8_PRIO
 #define DEC8_PRIO 0
 #endif
@@ -155,6 +161,20 @@ __device__ __forceinline__ void act_kstep(const f32x4 &x0, const f32x4 &x1, cons
   lo = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
 }
 
+// one quarter of act_kstep: values 2 part' .. 2 part' + 1 of tile (part >> 1) -> word `part` of the fragment pair
+template <bool WITH_LO, int PART>
+__device__ __forceinline__ void act_slice(const f32x4 &x0, const f32x4 &x1, const float *S, const float *T, int ch,
+                                          u32x4 &hiw, u32x4 &low, unsigned &amax16) {
+  constexpr int o = 2 * (PART & 1) + 16 * (PART >> 1);
+  const f32x4 &x = (PART >> 1) ? x1 : x0;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 s2 = *reinterpret_cast<const f32x2 *>(S + ch + o), t2 = *reinterpret_cast<const f32x2 *>(T + ch + o);
+  unsigned h, l;
+  act2<WITH_LO>(x[2 * (PART & 1)], x[2 * (PART & 1) + 1], s2[0], s2[1], t2[0], t2[1], h, l, amax16);
+  hiw[PART] = h;
+  low[PART] = l;
+}
+
 // wave w moves fragments 4w..4w+3 of a half
 __device__ __forceinline__ void dma_piece8(const half8 *__restrict__ packed, unsigned char *s_slots, int h, int j,
                                            int wave, int lane) {
@@ -218,8 +238,10 @@ __device__ __forceinline__ void frag_wait(Frag4 &d) { (void)d; }
 template <int OFF>
 __device__ __forceinline__ void frag_issue(Frag4 &d, const half8 *base) {
   const unsigned addr = lds_addr(base);
+  // s_nop 3: hipcc does not pad an asm statement -- a destination may be a register some MFMA read as SrcC just
+  // before (an accumulator chain that changed registers); the 4-pass XDL write-after-read distance is 3 wait states
   asm volatile(
-      "ds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c6\n\t"
+      "s_nop 3\n\tds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c6\n\t"
       "ds_read_b128 %2, %4 offset:%c7\n\tds_read_b128 %3, %4 offset:%c8"
       : "=&v"(d.h0), "=&v"(d.l0), "=&v"(d.h1), "=&v"(d.l1)
       : "v"(addr), "i"(OFF), "i"(OFF + 1024), "i"(OFF + 2048), "i"(OFF + 3072));
@@ -292,8 +314,11 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
       f32x4 *dst = reinterpret_cast<f32x4 *>(s_tab);
       for (int i = t; i < ROWS * H / 4; i += 512) dst[i] = src[i];
       if (!ring_primed) {
-        for (int i = t; i < H * 3; i += 512) s_wp[i] = fc_p_w[i];
-        if (t < H) s_wo[t] = fc_out_w[t];
+        int tt = t;
+        asm volatile("" : "+v"(tt));     // once per kernel: keep these two per-lane addresses from being hoisted out of
+                                         // the tile loop and held (spilled) for its whole duration
+        for (int i = tt; i < H * 3; i += 512) s_wp[i] = fc_p_w[i];
+        if (tt < H) s_wo[tt] = fc_out_w[tt];
       }
       cur_prop = prop;
     }
@@ -376,12 +401,18 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
       step_fence();
       __syncthreads();
 
+#if DEC8_ROT && DEC8_PIPE
+      half8 bhi, blo;       // a2' of slab 0; slabs 1-7 get theirs from the slices inside the previous slab's phase B
+      act_kstep<X3>(acc_cur[0], acc_cur[1], S1, T1, g4, bhi, blo, amax16);
+#endif
       for (int mb = 0; mb < 8; ++mb) {
         const int c = blk * 8 + mb;
         // ---- epilogue of fc_0 block mb -> a2' (the B operand of fc_1's k-slab mb)
         f32x4 acc_next[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#if !(DEC8_ROT && DEC8_PIPE)
         half8 bhi, blo;
         act_kstep<X3>(acc_cur[0], acc_cur[1], S1, T1, 32 * mb + g4, bhi, blo, amax16);
+#endif
         auto issue_dma = [&](int j) {          // piece j (0..7) of this slab's two halves
 #if DEC8_NODMA
           (void)j;
@@ -402,6 +433,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
         const half8 *aA = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 2) & 3) * HALF_BYTES) + lane;
         const half8 *aB = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 1) & 3) * HALF_BYTES) + lane;
         Frag4 fs[3];
+#if DEC8_PIPE
+        u32x4 nhw = {0u, 0u, 0u, 0u}, nlw = {0u, 0u, 0u, 0u};       // the next slab's a2' words, filled by the slices
+#endif
         if (mb < 7) {
           frag_issue<0>(fs[0], aA);
           static_for<0, 8>([&](auto kc) {
@@ -435,6 +469,10 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           step_fence();
           frag_wait(cur);
           if constexpr (tp < 7) frag_issue<4096 * (tp + 1)>(nxt, aB);
+#if DEC8_PIPE
+          if constexpr (tp >= 1 && tp <= 4)
+            if (mb < 7) act_slice<X3, tp - 1>(acc_next[0], acc_next[1], S1, T1, 32 * (mb + 1) + g4, nhw, nlw, amax16);
+#endif
           Hs[2 * tp] = mfma16(cur.h0, bhi, Hs[2 * tp]);
           Hs[2 * tp + 1] = mfma16(cur.h1, bhi, Hs[2 * tp + 1]);
           if (X3) {
@@ -515,8 +553,13 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
                             // right in front of the next slab's conditioning-table loads into the registers they read)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#if DEC8_ROT && DEC8_PIPE
+        bhi = __builtin_bit_cast(half8, nhw);
+        blo = __builtin_bit_cast(half8, nlw);
+#else
         acc_cur[0] = acc_next[0];
         acc_cur[1] = acc_next[1];
+#endif
       }
     }
 

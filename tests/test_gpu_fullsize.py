@@ -34,7 +34,14 @@ from rfdnet_amd.iscnet.network import ISCNet
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-4
-HAUSDORFF_CELLS = 1e-3      # vertex agreement of the CPU and HIP meshes where no inside / outside decision differs
+# Mesh agreement of the CPU and HIP paths where no inside / outside decision differs.  A vertex sits at
+# t = (thr - a) / (b - a) on its grid edge, so a logit difference d moves it by ~d / |b - a| cells: on the flat
+# stretches of a random-weight field (|b - a| ~ 1e-5, >1000 logits within 1e-4 of the threshold per proposal) the
+# measured 5.5e-7 logit difference is 1-4 % of a cell (first GPU run: 7.8e-3 .. 3.7e-2).  The bound that does not
+# depend on the field's slope is in LOGIT units: the CPU value grid, interpolated along its edge at every HIP vertex,
+# must sit on the threshold to within the logit tolerance (oracle/parity.py iso_residual; measured ~1e-6).
+ISO_RESIDUAL_LOGIT = 1e-5
+HAUSDORFF_CELLS = 0.5       # same edge, by a wide margin
 PICK = (0, 97, 255)
 
 
@@ -166,7 +173,8 @@ def test_cpu_path_vs_hip_path_occupancy_and_mesh_parity(scene, oracle):
     (test_epoch.py:10-68 -> generator.py:99-117 MISE loop -> :145-197 marching cubes; oracle restatements) and on the
     GPU.  MISE is data dependent, so a logit within ~1e-6 of the threshold may be refined on one side and filled
     on the other; everything else must agree: IoU of `grid >= thr` >= 0.9999, identical face counts where the CPU
-    grid holds no logit within 1e-4 of the threshold, vertex Hausdorff distance in cells printed and bounded."""
+    grid holds no logit within 1e-4 of the threshold, and where no decision flipped every HIP vertex on the CPU
+    field's iso-surface to 1e-5 logit (vertex Hausdorff distance in cells printed; it scales with 1 / slope)."""
     from oracle import parity
     net, gen, codes, cls, grids, stats = scene
     if gen.upsampling_steps == 0:
@@ -194,15 +202,19 @@ def test_cpu_path_vs_hip_path_occupancy_and_mesh_parity(scene, oracle):
         r = parity.compare(grids[k].cpu().numpy(), meshes[j].vertices.cpu().numpy(), meshes[j].faces.cpu().numpy(),
                            cpu_grid, thr, gen.padding)
         print("proposal %3d (inside %.4f, %d CPU queries): IoU %.6f, %d flips, %d logits within 1e-4 of thr, "
-              "max |dlogit| %.2e (%d points > 1e-4), faces %d / %d, vertex Hausdorff %.2e cells"
+              "max |dlogit| %.2e (%d points > 1e-4), faces %d / %d, vertex Hausdorff %.2e cells, HIP vertices on the "
+              "CPU iso-surface to %.2e logit (%d interior vertices)"
               % (k, float(inside[k]), n_q, r["iou"], r["flips"], r["near_threshold"], r["max_abs_dlogit"],
-                 r["points_off_1e-4"], r["faces_hip"], r["faces_cpu"], r["hausdorff_cells"]))
+                 r["points_off_1e-4"], r["faces_hip"], r["faces_cpu"], r["hausdorff_cells"], r["iso_residual_logit"],
+                 r["iso_vertices_checked"]))
         assert r["iou"] >= 0.9999, r
         if r["near_threshold"] == 0:
             assert r["faces_hip"] == r["faces_cpu"] and r["flips"] == 0, r
+        assert r["points_off_1e-4"] <= 64 * max(1, r["flips"]), r     # a flipped subdivision fills instead of evaluating
         if r["flips"] == 0:
             # same topology: the meshes differ only through |dlogit| / |gradient| on the crossing edges
             assert r["hausdorff_cells"] <= HAUSDORFF_CELLS, r
+            assert r["iso_residual_logit"] <= ISO_RESIDUAL_LOGIT, r
         worst_iou, worst_h = min(worst_iou, r["iou"]), max(worst_h, r["hausdorff_cells"])
     print("parity over %d proposals: min IoU %.6f, max vertex Hausdorff %.2e cells" % (len(picks), worst_iou, worst_h))
 

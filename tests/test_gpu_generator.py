@@ -176,8 +176,10 @@ def test_generator_mise_grid_matches_reference(hip, onet_and_fixture, tag, res0,
     flips = (grids > 0) != (ref > 0)
     print("%s: %d of %d grid points differ by > 1e-4 (max |d| %.3g), %d sign flips"
           % (tag, int(bad.sum()), bad.size, float(np.abs(grids - ref).max()), int(flips.sum())))
-    assert bad.mean() < 1e-3, bad.mean()
-    assert flips.mean() < 1e-4
+    # observed on MI355X (rounds 2 and 3): 0 of 107 811 points off, 0 flips; one flipped subdivision would move at most
+    # one coarse voxel's worth of fine points (<= 27 at one upsampling step) -- allow exactly that much
+    assert int(bad.sum()) <= 27, int(bad.sum())
+    assert int(flips.sum()) <= 1, int(flips.sum())
 
 
 def test_scatter_fused_into_the_decoder_gives_the_same_grids(hip, onet_and_fixture):

@@ -20,13 +20,13 @@ POISON = 0xA5
 class Guards(object):
     def __init__(self):
         self.live = []
-        self._orig = {}
+        self._orig = {name: getattr(torch, name) for name in ("empty", "zeros", "full")}
 
     def _alloc(self, shape, dtype, device, fill=None):
         n = int(np.prod(shape)) if len(shape) else 1
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        nbytes = n * self._orig["empty"]((), dtype=dtype).element_size()
         pad = (-nbytes) % 256
-        base = torch.full((GUARD + nbytes + pad + GUARD,), POISON, dtype=torch.uint8, device=device)
+        base = self._orig["full"]((GUARD + nbytes + pad + GUARD,), POISON, dtype=torch.uint8, device=device)
         view = base[GUARD:GUARD + nbytes].view(dtype).view(shape)
         if fill is not None:
             view.fill_(fill)
@@ -34,8 +34,7 @@ class Guards(object):
         return view
 
     def _wrap(self, name):
-        orig = getattr(torch, name)
-        self._orig[name] = orig
+        orig = self._orig[name]
 
         def fn(*args, **kw):
             dev = kw.get("device")

@@ -10,6 +10,7 @@
 //     DEP 1 = the decoder's shape: two accumulator chains, each MFMA takes the result of the one two earlier as
 //             SrcC, so the later ones wait in the matrix pipe for their producer -- and for the partner's MFMAs
 //     the overwrite is a ds_read_b128 (asynchronous: lands when LDS returns it)
+//     BAR 1 = every iteration starts behind an s_barrier that all eight waves take (the decoder's slab boundary)
 //   PRIO 0: all waves equal   1: aggressors raised (s_setprio 3)
 // A non-zero "bad" count = the distance was not enough under that arrangement.
 // Build: hipcc --offload-arch=gfx950 -O2 -o rfdnet_amd/lib/micro/mfma_war tools/micro/mfma_war.hip ; run: mfma_war [iters]
@@ -25,9 +26,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CHAIN(A, B)    M_("%[d0]", A, B, "0") M_("%[d1]", A, B, "0") M_("%[d0]", A, B, "%[d0]") \
                        M_("%[d1]", A, B, "%[d1]") M_("%[d0]", A, B, "%[d0]") M_("%[d1]", A, B, "%[d1]")
 #define FILL ".rept %c[gap]\n v_mfma_f32_16x16x32_f16 %[f], %[x], %[x], %[f]\n .endr\n .rept %c[nw]\n s_nop 0\n .endr\n"
+#define BARRIER_ ".if %c[bar]\n s_barrier\n .endif\n"
 #define OVER_LDS "ds_read_b128 %[r], %[addr]\n s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15\n"
 
-template <int VICTIM, int DEP, int WR, int NWAIT, int GAP, int PRIO>
+template <int VICTIM, int DEP, int BAR, int NWAIT, int GAP, int PRIO>
 __global__ __launch_bounds__(512) void war_kernel(int iters, unsigned *bad) {
   __shared__ __attribute__((aligned(16))) float s_pat[8][64][4];   // pattern p: 16 bytes per lane
   __shared__ int s_done;
@@ -51,13 +53,26 @@ __global__ __launch_bounds__(512) void war_kernel(int iters, unsigned *bad) {
     f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
     half8 w = ones;
     w[lane & 7] = (_Float16)0.5f;
-    do {
+    if (BAR) {
+      // the decoder's situation at a slab boundary: all eight waves leave an s_barrier together and both waves of a
+      // SIMD want the matrix pipe at once
+      for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-      for (int i = 0; i < 48; ++i) {
-        a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, ones, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, ones, a1, 0, 0, 0);
+        for (int i = 0; i < 24; ++i) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, ones, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, ones, a1, 0, 0, 0);
+        }
       }
-    } while (*(volatile int *)&s_done < 4);
+    } else {
+      do {
+#pragma unroll
+        for (int i = 0; i < 48; ++i) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, ones, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, ones, a1, 0, 0, 0);
+        }
+      } while (*(volatile int *)&s_done < 4);
+    }
     if (a0[0] + a1[0] == -1.f) bad[63] = 1;
   } else {
     unsigned nbad[6] = {0, 0, 0, 0, 0, 0};
@@ -71,37 +86,37 @@ __global__ __launch_bounds__(512) void war_kernel(int iters, unsigned *bad) {
         const unsigned nv = 0x44004400u;    // 4.0, 4.0
         if (DEP == 0) {
           if (VICTIM == 0)
-            asm volatile("s_nop 4\n" INDEP("%[r]", "%[b]", "0") FILL OVER_LDS
+            asm volatile("s_nop 4\n" BARRIER_ INDEP("%[r]", "%[b]", "0") FILL OVER_LDS
                          : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5),
                            [r] "+v"(r), [f] "+v"(f)
-                         : [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [nv] "v"(nv) : "memory");
+                         : [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [bar] "n"(BAR), [nv] "v"(nv) : "memory");
           else
-            asm volatile("s_nop 4\n" INDEP("%[b]", "%[r]", "0") FILL OVER_LDS
+            asm volatile("s_nop 4\n" BARRIER_ INDEP("%[b]", "%[r]", "0") FILL OVER_LDS
                          : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5),
                            [r] "+v"(r), [f] "+v"(f)
-                         : [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [nv] "v"(nv) : "memory");
+                         : [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [bar] "n"(BAR), [nv] "v"(nv) : "memory");
           expect = 32.f * (p + 1);
         } else {
           if (VICTIM == 0)
-            asm volatile("s_nop 4\n" CHAIN("%[r]", "%[b]") FILL OVER_LDS
+            asm volatile("s_nop 4\n" BARRIER_ CHAIN("%[r]", "%[b]") FILL OVER_LDS
                          : [d0] "+v"(d0), [d1] "+v"(d1), [r] "+v"(r), [f] "+v"(f)
-                         : [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [nv] "v"(nv) : "memory");
+                         : [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [bar] "n"(BAR), [nv] "v"(nv) : "memory");
           else
-            asm volatile("s_nop 4\n" CHAIN("%[b]", "%[r]") FILL OVER_LDS
+            asm volatile("s_nop 4\n" BARRIER_ CHAIN("%[b]", "%[r]") FILL OVER_LDS
                          : [d0] "+v"(d0), [d1] "+v"(d1), [r] "+v"(r), [f] "+v"(f)
-                         : [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [nv] "v"(nv) : "memory");
+                         : [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [bar] "n"(BAR), [nv] "v"(nv) : "memory");
           expect = 3.f * 32.f * (p + 1);
         }
         if (r[0] != (_Float16)(float)(q + 1)) nbad[5] += 1u << 16;      // the overwrite itself must have happened
       } else {                              // R = SrcC (f32), independent MFMAs
         f32x4 r = *reinterpret_cast<f32x4 *>(s_pat[p][lane]);
         const float nv = 7777.f;
-        asm volatile("s_nop 4\n" INDEP("%[a]", "%[b]", "%[r]") FILL OVER_LDS
+        asm volatile("s_nop 4\n" BARRIER_ INDEP("%[a]", "%[b]", "%[r]") FILL OVER_LDS
                      : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5),
                        [r] "+v"(r), [f] "+v"(f)
-                     : [a] "v"(ones), [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [nv] "v"(nv) : "memory");
+                     : [a] "v"(ones), [b] "v"(ones), [x] "v"(ones), [addr] "v"(addr), [nw] "n"(NWAIT), [gap] "n"(GAP), [bar] "n"(BAR), [nv] "v"(nv) : "memory");
         expect = 32.f + 1000.f * (p + 1);
-        if (r[0] != (WR ? 7777.f : 1000.f * (q + 1))) nbad[5] += 1u << 16;
+        if (r[0] != 1000.f * (q + 1)) nbad[5] += 1u << 16;
       }
       const f32x4 *d[6] = {&d0, &d1, &d2, &d3, &d4, &d5};
 #pragma unroll
@@ -119,35 +134,35 @@ __global__ __launch_bounds__(512) void war_kernel(int iters, unsigned *bad) {
 
 static unsigned g_total = 0;
 
-template <int VICTIM, int DEP, int WR, int NWAIT, int GAP, int PRIO>
+template <int VICTIM, int DEP, int BAR, int NWAIT, int GAP, int PRIO>
 static void run(unsigned *d_bad, int iters) {
   (void)hipMemset(d_bad, 0, 64 * sizeof(unsigned));
-  hipLaunchKernelGGL((war_kernel<VICTIM, DEP, WR, NWAIT, GAP, PRIO>), dim3(512), dim3(512), 0, 0, iters, d_bad);
+  hipLaunchKernelGGL((war_kernel<VICTIM, DEP, BAR, NWAIT, GAP, PRIO>), dim3(512), dim3(512), 0, 0, iters, d_bad);
   unsigned h[64];
   if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(1); }
   (void)hipMemcpy(h, d_bad, sizeof(h), hipMemcpyDeviceToHost);
   unsigned tot = 0;
-  printf("R=%s %s by=%s gap=%d nwait=%2d prio=%s : bad lane-results per checked MFMA", VICTIM == 0 ? "SrcA" : VICTIM == 1 ? "SrcB" : "SrcC",
-         DEP ? "chains" : "indep ", WR ? "v_mov  " : "ds_read", GAP, NWAIT, PRIO == 0 ? "equal      " : "aggr-raised");
+  printf("R=%s %s %s gap=%d nwait=%2d prio=%s : bad lane-results per checked MFMA", VICTIM == 0 ? "SrcA" : VICTIM == 1 ? "SrcB" : "SrcC",
+         DEP ? "chains" : "indep ", BAR ? "after-barrier" : "free-running ", GAP, NWAIT, PRIO == 0 ? "equal      " : "aggr-raised");
   for (int i = 0; i < 6; ++i) { printf(" %u", h[i]); tot += h[i]; }
   printf("  %s\n", tot ? "BAD" : "ok");
   g_total += tot;
 }
 
-template <int VICTIM, int DEP, int WR, int GAP, int PRIO>
+template <int VICTIM, int DEP, int BAR, int GAP, int PRIO>
 static void waits(unsigned *d_bad, int iters) {
-  run<VICTIM, DEP, WR, 0, GAP, PRIO>(d_bad, iters);
-  run<VICTIM, DEP, WR, 4, GAP, PRIO>(d_bad, iters);
-  run<VICTIM, DEP, WR, 16, GAP, PRIO>(d_bad, iters);
-  run<VICTIM, DEP, WR, 64, GAP, PRIO>(d_bad, iters);
+  run<VICTIM, DEP, BAR, 0, GAP, PRIO>(d_bad, iters);
+  run<VICTIM, DEP, BAR, 4, GAP, PRIO>(d_bad, iters);
+  run<VICTIM, DEP, BAR, 16, GAP, PRIO>(d_bad, iters);
+  run<VICTIM, DEP, BAR, 64, GAP, PRIO>(d_bad, iters);
 }
 
-template <int VICTIM, int DEP, int WR, int PRIO>
+template <int VICTIM, int DEP, int BAR, int PRIO>
 static void gaps(unsigned *d_bad, int iters) {
-  waits<VICTIM, DEP, WR, 0, PRIO>(d_bad, iters);
-  waits<VICTIM, DEP, WR, 1, PRIO>(d_bad, iters);
-  waits<VICTIM, DEP, WR, 2, PRIO>(d_bad, iters);
-  waits<VICTIM, DEP, WR, 6, PRIO>(d_bad, iters);
+  waits<VICTIM, DEP, BAR, 0, PRIO>(d_bad, iters);
+  waits<VICTIM, DEP, BAR, 1, PRIO>(d_bad, iters);
+  waits<VICTIM, DEP, BAR, 2, PRIO>(d_bad, iters);
+  waits<VICTIM, DEP, BAR, 6, PRIO>(d_bad, iters);
 }
 
 int main(int argc, char **argv) {
@@ -165,6 +180,12 @@ int main(int argc, char **argv) {
   gaps<0, 1, 0, 1>(d_bad, iters);
   gaps<1, 1, 0, 0>(d_bad, iters);
   gaps<1, 1, 0, 1>(d_bad, iters);
+  // ... and right behind a barrier release (where the round-2 failing build had its sunk MFMAs and the loads on top)
+  gaps<0, 1, 1, 0>(d_bad, iters);
+  gaps<0, 1, 1, 1>(d_bad, iters);
+  gaps<1, 1, 1, 0>(d_bad, iters);
+  gaps<1, 1, 1, 1>(d_bad, iters);
+  waits<2, 0, 1, 0, 1>(d_bad, iters);
   printf("TOTAL bad %u (%d iterations x 512 workgroups x 4 victim waves per configuration)\n", g_total, iters);
   return 0;
 }
