@@ -28,12 +28,14 @@
 #ifndef DEC8_NODMA
 #define DEC8_NODMA 0
 #endif
-// Correctness experiments (tools/ab/prio_check.py, profiles/r03_decoder_hazard.txt):
-//   DEC8_ROT   1 = weight-fragment prefetch through three rotating register sets whose disjointness from the
-//                  operands of the previous k-step's MFMAs is guaranteed by the asm constraints (shipped);
-//              0 = round 2's compiler-allocated two-set prefetch (the form that failed under static priority)
-//   DEC8_FENCE 1 = round 2's scheduling fence after every LDS-DMA issue
-//   DEC8_PRIO  1 = static s_setprio 1 for waves 4-7 (the arrangement that exposed the failure)
+// Build switches (tools/ab/build_variants.py; profiles/r03_decoder_hazard.txt, profiles/r03_decoder_ablation.txt):
+//   DEC8_ROT   1 = weight-fragment prefetch through three rotating register sets, k-steps fenced (shipped);
+//              0 = round 2's compiler-placed two-set prefetch (kept as the control of the ISA audit and for A/B)
+//   DEC8_SB    1 = sched_barrier at every k-step boundary and in front of every barrier (part of DEC8_ROT 1)
+//   DEC8_FENCE 1 = round 2's scheduling fence after every LDS-DMA issue (DEC8_ROT 0 only)
+//   DEC8_PRIO  1 = static s_setprio 1 for waves 4-7 (the arrangement that exposed round 2's failure; not shipped)
+//   DEC8_DMA_AUX cache policy bits of the LDS-DMA weight stream (aux operand of global_load_lds: 2 = nt, shipped:
+//              -0.3 % .. -0.4 % kernel time, every workgroup streams the same 2.6 MB once per tile)
 #ifndef DEC8_ROT
 #define DEC8_ROT 1
 #endif
@@ -43,18 +45,11 @@
 #ifndef DEC8_SB
 #define DEC8_SB 1
 #endif
-//   DEC8_PIPE  1 = the CBN + ReLU + split of fc_0's block mb+1 (the B operand of the NEXT slab's fc_1 MFMAs) is cut into
-//                  four slices issued inside steps 1-4 of this slab's phase B, under its MFMAs, instead of standing
-//                  in front of the next slab with the matrix pipe idle (both waves of a SIMD convert at the same time)
-#ifndef DEC8_PIPE
-#define DEC8_PIPE 1
-#endif
 #ifndef DEC8_PRIO
 #define DEC8_PRIO 0
 #endif
-// cache policy bits of the LDS-DMA weight stream (aux operand of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1)
 #ifndef DEC8_DMA_AUX
-#define DEC8_DMA_AUX 0
+#define DEC8_DMA_AUX 2
 #endif
 
 namespace {
@@ -161,20 +156,6 @@ __device__ __forceinline__ void act_kstep(const f32x4 &x0, const f32x4 &x1, cons
   lo = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
 }
 
-// one quarter of act_kstep: values 2 part' .. 2 part' + 1 of tile (part >> 1) -> word `part` of the fragment pair
-template <bool WITH_LO, int PART>
-__device__ __forceinline__ void act_slice(const f32x4 &x0, const f32x4 &x1, const float *S, const float *T, int ch,
-                                          u32x4 &hiw, u32x4 &low, unsigned &amax16) {
-  constexpr int o = 2 * (PART & 1) + 16 * (PART >> 1);
-  const f32x4 &x = (PART >> 1) ? x1 : x0;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 s2 = *reinterpret_cast<const f32x2 *>(S + ch + o), t2 = *reinterpret_cast<const f32x2 *>(T + ch + o);
-  unsigned h, l;
-  act2<WITH_LO>(x[2 * (PART & 1)], x[2 * (PART & 1) + 1], s2[0], s2[1], t2[0], t2[1], h, l, amax16);
-  hiw[PART] = h;
-  low[PART] = l;
-}
-
 // wave w moves fragments 4w..4w+3 of a half
 __device__ __forceinline__ void dma_piece8(const half8 *__restrict__ packed, unsigned char *s_slots, int h, int j,
                                            int wave, int lane) {
@@ -196,23 +177,20 @@ __device__ __forceinline__ void dma_piece8(const half8 *__restrict__ packed, uns
 
 // ---- weight-fragment prefetch with PROVABLY disjoint destinations --------------------------------------------
 // A k-step's four fragments (hi/lo of two channel tiles) are fetched one step ahead.  Round 2 let the compiler
-// place them: it reused the registers the previous step's MFMAs had just read as SrcA (0-6 wait states earlier),
-// and a build with unequal wave priorities returned wrong 16-point groups (profiles/r02_decoder_ablation.txt
-// section 5, profiles/r03_decoder_hazard.txt).  Now THREE sets rotate -- in use (cur), in flight (nxt), last read
-// (prv) -- and the structure, not the allocator's mood, keeps them apart:
-//   * step_fence(): nothing is scheduled across a k-step boundary (hipcc otherwise sinks the register-only MFMAs
-//     of step k-2 below the prefetch of step k);
+// place them: it reused the registers the previous step's MFMAs had just read as SrcA (0-6 wait states earlier) and
+// sank a slab's last MFMAs below the slab-end barrier, right in front of the next slab's loads into their source
+// registers; with unequal wave priorities that build returned wrong 16-point groups (profiles/r03_decoder_hazard.txt:
+// reproduced from the git history in round 3, 10/10 cold processes; ONE sched_barrier in front of the barrier makes
+// it clean).  Now THREE sets rotate -- in use (cur), in flight (nxt), last read (prv) -- and the structure, not the
+// allocator's mood, keeps them apart:
+//   * step_fence(): nothing is scheduled across a k-step boundary or across a barrier;
 //   * keep_alive(cur, prv) at the END of every step: both sets stay allocated for the whole step, so neither the
 //     prefetch destinations nor any other load issued in step k (conditioning-table reads) can be given a register
 //     that the MFMAs of step k or k-1 read.  A destination was therefore last read >= one whole k-step (six
 //     MFMAs) earlier.  tools/audit_mfma_war.py checks exactly that on the generated assembly (CPU suite).
-// DEC8_ROT 1: the prefetch is an asm statement (invisible to hipcc's lgkmcnt bookkeeping: frag_wait() = lgkmcnt(0)
-// naming the destinations stands before the first use; LDS returns in order, so hipcc's own counted waits only
-// ever over-wait).  DEC8_ROT 2: plain loads, hipcc counts them and pads MFMA-SrcC write-after-read states itself.
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
-}
-
+// The loads themselves are plain loads: hipcc counts them (lgkmcnt) and pads the MFMA-SrcC write-after-read states
+// itself.  (An asm-issued variant measured 1 % faster in one build and returned WRONG logits in another: hipcc may
+// copy an asm load's destination register before the data has landed -- it does not know the load is in flight.)
 struct Frag4 {
   half8 h0, l0, h1, l1;
 };
@@ -224,32 +202,19 @@ __device__ __forceinline__ void keep_alive(const Frag4 &a) {
   asm volatile("" ::"v"(a.h0), "v"(a.l0), "v"(a.h1), "v"(a.l1));
 }
 
-#if DEC8_ROT == 2
 template <int OFF>
 __device__ __forceinline__ void frag_issue(Frag4 &d, const half8 *base) {
+#if DEC8_NOREAD
+  (void)base;
+  d.h0 = d.l0 = d.h1 = d.l1 = half8{};
+#else
   const half8 *w = base + OFF / 16;
   d.h0 = w[0];
   d.l0 = w[64];
   d.h1 = w[128];
   d.l1 = w[192];
-}
-__device__ __forceinline__ void frag_wait(Frag4 &d) { (void)d; }
-#else
-template <int OFF>
-__device__ __forceinline__ void frag_issue(Frag4 &d, const half8 *base) {
-  const unsigned addr = lds_addr(base);
-  // s_nop 3: hipcc does not pad an asm statement -- a destination may be a register some MFMA read as SrcC just
-  // before (an accumulator chain that changed registers); the 4-pass XDL write-after-read distance is 3 wait states
-  asm volatile(
-      "s_nop 3\n\tds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c6\n\t"
-      "ds_read_b128 %2, %4 offset:%c7\n\tds_read_b128 %3, %4 offset:%c8"
-      : "=&v"(d.h0), "=&v"(d.l0), "=&v"(d.h1), "=&v"(d.l1)
-      : "v"(addr), "i"(OFF), "i"(OFF + 1024), "i"(OFF + 2048), "i"(OFF + 3072));
-}
-__device__ __forceinline__ void frag_wait(Frag4 &d) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d.h0), "+v"(d.l0), "+v"(d.h1), "+v"(d.l1));
-}
 #endif
+}
 
 // Nothing is scheduled across a k-step boundary (see above).
 __device__ __forceinline__ void step_fence() {
@@ -356,7 +321,6 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           constexpr int ks = decltype(kc)::value;
           Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
           step_fence();
-          frag_wait(cur);
           if constexpr (ks < 7) frag_issue<4096 * (ks + 1)>(nxt, a0);
           if constexpr (ks < 7)
             act_kstep<X3>(Hs[2 * ks + 2], Hs[2 * ks + 3], S0, T0, 32 * (ks + 1) + g4, ahi[ks + 1], alo[ks + 1], amax16);
@@ -401,18 +365,12 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
       step_fence();
       __syncthreads();
 
-#if DEC8_ROT && DEC8_PIPE
-      half8 bhi, blo;       // a2' of slab 0; slabs 1-7 get theirs from the slices inside the previous slab's phase B
-      act_kstep<X3>(acc_cur[0], acc_cur[1], S1, T1, g4, bhi, blo, amax16);
-#endif
       for (int mb = 0; mb < 8; ++mb) {
         const int c = blk * 8 + mb;
         // ---- epilogue of fc_0 block mb -> a2' (the B operand of fc_1's k-slab mb)
         f32x4 acc_next[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#if !(DEC8_ROT && DEC8_PIPE)
         half8 bhi, blo;
         act_kstep<X3>(acc_cur[0], acc_cur[1], S1, T1, 32 * mb + g4, bhi, blo, amax16);
-#endif
         auto issue_dma = [&](int j) {          // piece j (0..7) of this slab's two halves
 #if DEC8_NODMA
           (void)j;
@@ -433,16 +391,12 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
         const half8 *aA = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 2) & 3) * HALF_BYTES) + lane;
         const half8 *aB = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 1) & 3) * HALF_BYTES) + lane;
         Frag4 fs[3];
-#if DEC8_PIPE
-        u32x4 nhw = {0u, 0u, 0u, 0u}, nlw = {0u, 0u, 0u, 0u};       // the next slab's a2' words, filled by the slices
-#endif
         if (mb < 7) {
           frag_issue<0>(fs[0], aA);
           static_for<0, 8>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
             Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
             step_fence();
-            frag_wait(cur);
             if constexpr (ks < 7) frag_issue<4096 * (ks + 1)>(nxt, aA);
             else frag_issue<0>(nxt, aB);
             issue_dma(ks);
@@ -467,12 +421,7 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           constexpr int ks = 8 + tp;
           Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
           step_fence();
-          frag_wait(cur);
           if constexpr (tp < 7) frag_issue<4096 * (tp + 1)>(nxt, aB);
-#if DEC8_PIPE
-          if constexpr (tp >= 1 && tp <= 4)
-            if (mb < 7) act_slice<X3, tp - 1>(acc_next[0], acc_next[1], S1, T1, 32 * (mb + 1) + g4, nhw, nlw, amax16);
-#endif
           Hs[2 * tp] = mfma16(cur.h0, bhi, Hs[2 * tp]);
           Hs[2 * tp + 1] = mfma16(cur.h1, bhi, Hs[2 * tp + 1]);
           if (X3) {
@@ -553,13 +502,8 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
                             // right in front of the next slab's conditioning-table loads into the registers they read)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#if DEC8_ROT && DEC8_PIPE
-        bhi = __builtin_bit_cast(half8, nhw);
-        blo = __builtin_bit_cast(half8, nlw);
-#else
         acc_cur[0] = acc_next[0];
         acc_cur[1] = acc_next[1];
-#endif
       }
     }
 
@@ -591,7 +535,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           pstate[(size_t)prop * n_per + l] = 2;
         }
       } else {
-        logits[pidx] = part + fc_out_b;
+        size_t po = pidx;
+        asm volatile("" : "+v"(po));      // once per tile: no per-lane store address held (spilled) across the whole tile loop
+        logits[po] = part + fc_out_b;
       }
     }
   }

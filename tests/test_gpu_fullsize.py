@@ -210,7 +210,10 @@ def test_cpu_path_vs_hip_path_occupancy_and_mesh_parity(scene, oracle):
         assert r["iou"] >= 0.9999, r
         if r["near_threshold"] == 0:
             assert r["faces_hip"] == r["faces_cpu"] and r["flips"] == 0, r
-        assert r["points_off_1e-4"] <= 64 * max(1, r["flips"]), r     # a flipped subdivision fills instead of evaluating
+        # a flipped subdivision decision FILLS a coarse voxel's fine points on one side and EVALUATES them on the other
+        # (mise.pyx:142-163), and its children may split again: up to 5^3 fine points per level-0 voxel at two
+        # upsampling steps, a few voxels per flip (measured: 254 points for 1 flip at 128^3, 0 where nothing flipped)
+        assert r["points_off_1e-4"] <= (512 * r["flips"] if r["flips"] else 0), r
         if r["flips"] == 0:
             # same topology: the meshes differ only through |dlogit| / |gradient| on the crossing edges
             assert r["hausdorff_cells"] <= HAUSDORFF_CELLS, r

@@ -4,8 +4,9 @@ For every instruction that writes VGPRs ASYNCHRONOUSLY (ds_read*, global/buffer/
 their data lands whenever the memory pipe returns it, not in program order with the matrix pipe) find the most recent
 v_mfma that READ one of those registers as SrcA / SrcB / SrcC and report the distance in issued MFMAs and in wait
 states.  Rules (profiles/r03_decoder_hazard.txt):
-  A/B: a load destination must not alias SrcA or SrcB of any of the last `min_mfma_gap` MFMAs
-       (round 2's failing decoder reused the registers of the MFMAs issued 3-6 wait states earlier);
+  A/B: a load destination must not alias SrcA or SrcB of any of the last `min_mfma_gap` MFMAs, unless that MFMA is
+       at least 32 wait states back (round 2's failing decoder reused the registers of the MFMAs issued 0-6 wait
+       states earlier);
   C:   a load destination that aliases SrcC of a recent MFMA must be at least `min_c_states` wait states behind it
        (the distance hipcc's own hazard recognizer keeps; inline-asm loads are not padded by hipcc, so this is the
        check that an asm-issued ds_read did not land on a just-read accumulator).
@@ -16,6 +17,8 @@ usage: audit_mfma_war.py file.s kernel_symbol_substring [min_mfma_gap=6] [min_c_
 import re
 import sys
 
+AB_STATES_OK = 32     # ... or this many wait states behind the reading MFMA (round 2: 32 wait states in front of the
+                      # prefetch made the failing build clean)
 LOADS = ("ds_read", "ds_load", "global_load", "buffer_load", "flat_load", "scratch_load")
 
 
@@ -115,7 +118,7 @@ def audit(path, sym, min_mfma_gap=6, min_c_states=6):
                         else:
                             if stats['min_ab_gap'] is None or h[4] < stats['min_ab_gap']:
                                 stats['min_ab_gap'] = h[4]
-                            if h[4] < min_mfma_gap:
+                            if h[4] < min_mfma_gap and h[3] < AB_STATES_OK:
                                 problems[(li, ml, kind)] = (start + li + 1, mn + ' ' + ops, start + ml + 1,
                                                             'Src' + kind.upper(), h[4], h[3])
             for h in hist.values():

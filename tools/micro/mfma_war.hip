@@ -13,7 +13,7 @@
 //     BAR 1 = every iteration starts behind an s_barrier that all eight waves take (the decoder's slab boundary)
 //   PRIO 0: all waves equal   1: aggressors raised (s_setprio 3)
 // A non-zero "bad" count = the distance was not enough under that arrangement.
-// Build: hipcc --offload-arch=gfx950 -O2 -o rfdnet_amd/lib/micro/mfma_war tools/micro/mfma_war.hip ; run: mfma_war [iters]
+// Build: hipcc --offload-arch=gfx950 -O2 -o rfdnet_amd/lib/micro/mfma_war tools/micro/mfma_war.hip ; run: mfma_war [iters] [bcast 0|1]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define OVER_LDS "ds_read_b128 %[r], %[addr]\n s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15\n"
 
 template <int VICTIM, int DEP, int BAR, int NWAIT, int GAP, int PRIO>
-__global__ __launch_bounds__(512) void war_kernel(int iters, unsigned *bad) {
+__global__ __launch_bounds__(512) void war_kernel(int iters, unsigned *bad, int bcast) {
   __shared__ __attribute__((aligned(16))) float s_pat[8][64][4];   // pattern p: 16 bytes per lane
   __shared__ int s_done;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(512) void war_kernel(int iters, unsigned *bad) {
     unsigned nbad[6] = {0, 0, 0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
       const int p = it & 7, q = (it + 3) & 7;
-      const unsigned addr = (unsigned)(size_t)(&s_pat[q][lane][0]);      // LDS byte address of the NEW value
+      // LDS byte address of the NEW value; bcast: every lane reads the SAME 16 bytes (a conditioning-table read in the
+      // decoder: one bank access, the shortest LDS return there is) instead of its own 16 of a 1-KiB fragment
+      const unsigned addr = (unsigned)(size_t)(&s_pat[q][bcast ? 0 : lane][0]);
       f32x4 d0 = {0, 0, 0, 0}, d1 = d0, d2 = d0, d3 = d0, d4 = d0, d5 = d0, f = d0;
       float expect;
       if (VICTIM != 2) {                    // R = SrcA (0) or SrcB (1), f16 fragment
@@ -133,16 +135,17 @@ __global__ __launch_bounds__(512) void war_kernel(int iters, unsigned *bad) {
 }
 
 static unsigned g_total = 0;
+static int g_bcast = 0;
 
 template <int VICTIM, int DEP, int BAR, int NWAIT, int GAP, int PRIO>
 static void run(unsigned *d_bad, int iters) {
   (void)hipMemset(d_bad, 0, 64 * sizeof(unsigned));
-  hipLaunchKernelGGL((war_kernel<VICTIM, DEP, BAR, NWAIT, GAP, PRIO>), dim3(512), dim3(512), 0, 0, iters, d_bad);
+  hipLaunchKernelGGL((war_kernel<VICTIM, DEP, BAR, NWAIT, GAP, PRIO>), dim3(512), dim3(512), 0, 0, iters, d_bad, g_bcast);
   unsigned h[64];
   if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(1); }
   (void)hipMemcpy(h, d_bad, sizeof(h), hipMemcpyDeviceToHost);
   unsigned tot = 0;
-  printf("R=%s %s %s gap=%d nwait=%2d prio=%s : bad lane-results per checked MFMA", VICTIM == 0 ? "SrcA" : VICTIM == 1 ? "SrcB" : "SrcC",
+  printf("%s R=%s %s %s gap=%d nwait=%2d prio=%s : bad lane-results per checked MFMA", g_bcast ? "bcast" : "frag ", VICTIM == 0 ? "SrcA" : VICTIM == 1 ? "SrcB" : "SrcC",
          DEP ? "chains" : "indep ", BAR ? "after-barrier" : "free-running ", GAP, NWAIT, PRIO == 0 ? "equal      " : "aggr-raised");
   for (int i = 0; i < 6; ++i) { printf(" %u", h[i]); tot += h[i]; }
   printf("  %s\n", tot ? "BAD" : "ok");
@@ -167,6 +170,7 @@ static void gaps(unsigned *d_bad, int iters) {
 
 int main(int argc, char **argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 3000;
+  g_bcast = argc > 2 ? atoi(argv[2]) : 0;
   unsigned *d_bad;
   (void)hipMalloc(&d_bad, 64 * sizeof(unsigned));
   // LDS overwrite of SrcC / SrcA / SrcB, independent MFMAs
