@@ -308,24 +308,37 @@ class HipBackend(object):
         self.selfcheck = self.decoder_selfcheck(self.dec if hasattr(self, "dec") else self.nets[0].completion.decoder)
 
     def decoder_selfcheck(self, dec):
-        """After the timed region: the same multi-proposal ragged launch twice -- the two results must be
+        """After the timed region: the same multi-proposal ragged launch four times -- the results must be
         bit-identical (a race shows up as one wave's 16 points differing in one of the runs; the static-priority
-        build of round 2 failed exactly this check, profiles/r02_decoder_ablation.txt section 5)."""
+        build of round 2 failed exactly this check) -- AND agree with the independent four-wave kernel
+        (csrc/occ_decoder.hip: other MFMA shape, other fragment order, no shared scheduling) to a few ulps, so a
+        deterministic error of the shipped kernel cannot hide behind its own repeatability."""
         torch = self.torch
         g = torch.Generator(device=self.device).manual_seed(5)
         K, T = 8, 1024
         p = (torch.rand(K, T, 3, device=self.device, generator=g) - 0.5) * 1.1
         c = torch.randn(K, 512, device=self.device, generator=g)
         z = torch.zeros(K, 32, device=self.device)
+        orig = self.timers[0]._orig if hasattr(self.timers[0], "_orig") else dec.decode_tiles
         with torch.no_grad():
             table, fcp = dec.fold(z, c)
             tile_prop = torch.arange(K, dtype=torch.int32, device=self.device).repeat_interleave(T // 128)
             pts = p.reshape(-1, 3).contiguous()
-            runs = [self.timers[0]._orig(pts, tile_prop, table, fcp) for _ in range(4)]
+            runs = [orig(pts, tile_prop, table, fcp) for _ in range(4)]
+            kern = dec.kernel
+            other = "w4" if kern == "w8" else "w8"
+            try:
+                dec.kernel = other
+                ref = orig(pts, tile_prop, table, fcp)
+            finally:
+                dec.kernel = kern
         same = all(torch.equal(runs[0], r) for r in runs[1:])
         if not same:
             raise RuntimeError("decoder self-check: repeated launches on the same input differ")
-        return "4 launches of 8 x 1024 points bit-identical"
+        d = float((runs[0] - ref).abs().max())
+        if not d < 5e-6:
+            raise RuntimeError("decoder self-check: %s and %s kernels differ by %.3g" % (kern, other, d))
+        return "4 launches of 8 x 1024 points bit-identical; max |%s - %s kernel| = %.2e" % (kern, other, d)
 
     def kernel_name(self):
         return "%s<%d>" % ("occ_decode8_kernel" if self.nets[0].completion.decoder.kernel == "w8"
@@ -562,37 +575,55 @@ def run_job(args, be, rank, world, dist):
     return stats, single
 
 
+GROUP_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "group_traffic.json")
+
+
 def grouping_roofline(device):
     """HBM figure of the grouping family (north_star: "rocprof HBM GB/s reported for grouping"), measured
     live with HIP events on the stream the kernel is launched on: QueryAndGroup's fused epilogue
     (rfd_group_concat) at the SA2 layer's shape (131 channels x 1024 centres x 32 samples from a
-    2048-point table), B = 32 scenes per launch -- one scene (18.4 MB) is launch-bound.  Algorithmic
-    bytes per launch = 4 C M ns written + 4 M ns of indices + the (C, N) table and xyz read once."""
+    2048-point table), B = 32 scenes per launch (one scene, 18.4 MB, is launch-bound) and B = 8
+    beside it.  Algorithmic bytes per launch = 4 C M ns written + 4 M ns of indices + the (C, N) table and
+    xyz read once.  `traffic` = HBM bytes per launch from the committed PMC passes over the same launches
+    (profiles/group_traffic.json; counters cannot be read from inside this process)."""
     import torch
     from rfdnet_amd.pointnet2_ops import _ext
-    B, N, M, ns, C = 32, 2048, 1024, 32, 128
-    g = torch.Generator(device=device).manual_seed(0)
-    xyz = torch.rand(B, N, 3, device=device, generator=g)
-    ctr = xyz[:, :M].contiguous()
-    feats = torch.randn(B, C, N, device=device, generator=g)
-    idx = _ext.ball_query(ctr, xyz, 0.4, ns)
-    nbytes = B * ((3 + C) * M * ns * 4 + M * ns * 4 + C * N * 4 + N * 12 + M * 12)
-    for _ in range(3):
-        _ext.group_concat(xyz, ctr, feats, idx, 0.4, True, True, False)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    it = 10
-    e0.record()
-    for _ in range(it):
-        _ext.group_concat(xyz, ctr, feats, idx, 0.4, True, True, False)
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / it
-    ach = nbytes / ms / 1e6
-    return {"bound": "hbm", "kernel": "group_lds_kernel (rfd_group_concat, SA2 shape, 32 scenes per launch)",
-            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-            "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
-            "traffic": None, "note": "not on the headline path any more (the fused SA layer never materialises the "
-                                     "grouped tensor); reported because the grouping family is the path's HBM-bound op"}
+    try:
+        with open(GROUP_TRAFFIC_FILE) as fh:
+            pmc = json.load(fh)
+    except (OSError, ValueError):
+        pmc = {}
+    N, M, ns, C = 2048, 1024, 32, 128
+    out = {}
+    for B in (32, 8):
+        g = torch.Generator(device=device).manual_seed(0)
+        xyz = torch.rand(B, N, 3, device=device, generator=g)
+        ctr = xyz[:, :M].contiguous()
+        feats = torch.randn(B, C, N, device=device, generator=g)
+        idx = _ext.ball_query(ctr, xyz, 0.4, ns)
+        nbytes = B * ((3 + C) * M * ns * 4 + M * ns * 4 + C * N * 4 + N * 12 + M * 12)
+        for _ in range(3):
+            _ext.group_concat(xyz, ctr, feats, idx, 0.4, True, True, False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        it = 10
+        e0.record()
+        for _ in range(it):
+            _ext.group_concat(xyz, ctr, feats, idx, 0.4, True, True, False)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / it
+        ach = nbytes / ms / 1e6
+        t = pmc.get(str(B), {}).get("bytes_per_launch")
+        out[B] = {"achieved": ach, "frac": ach / 8000.0, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
+                  "traffic": t}
+    r = {"bound": "hbm", "kernel": "group_lds_kernel (rfd_group_concat, SA2 shape, 32 scenes per launch)",
+         "achieved": out[32]["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": out[32]["frac"],
+         "algorithmic_bytes_per_launch": out[32]["algorithmic_bytes_per_launch"], "avg_launch_ms": out[32]["avg_launch_ms"],
+         "traffic": out[32]["traffic"], "traffic_source": pmc.get("source"),
+         "b8": out[8],
+         "note": "not on the headline path any more (the fused SA layer never materialises the grouped tensor); "
+                 "reported because the grouping family is the path's HBM-bound op"}
+    return r
 
 
 def traffic_per_query():

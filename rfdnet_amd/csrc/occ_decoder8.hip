@@ -34,8 +34,10 @@
 //   DEC8_SB    1 = sched_barrier at every k-step boundary and in front of every barrier (part of DEC8_ROT 1)
 //   DEC8_FENCE 1 = round 2's scheduling fence after every LDS-DMA issue (DEC8_ROT 0 only)
 //   DEC8_PRIO  1 = static s_setprio 1 for waves 4-7 (the arrangement that exposed round 2's failure; not shipped)
-//   DEC8_DMA_AUX cache policy bits of the LDS-DMA weight stream (aux operand of global_load_lds: 2 = nt, shipped:
-//              -0.3 % .. -0.4 % kernel time, every workgroup streams the same 2.6 MB once per tile)
+//   DEC8_DMA_AUX cache policy bits of the LDS-DMA weight stream (aux operand of global_load_lds; 2 = nt measured
+//              -0.3 % .. -0.4 % kernel time but 1093 instead of 15 B of HBM traffic per query point -- the hint evicts
+//              the 2.6-MB stream every workgroup re-reads once per tile from L2 -- so it is NOT shipped:
+//              profiles/r03_decoder_traffic_nt.txt)
 #ifndef DEC8_ROT
 #define DEC8_ROT 1
 #endif
@@ -49,7 +51,10 @@
 #define DEC8_PRIO 0
 #endif
 #ifndef DEC8_DMA_AUX
-#define DEC8_DMA_AUX 2
+#define DEC8_DMA_AUX 0
+#endif
+#ifndef DEC8_WLO_BITS
+#define DEC8_WLO_BITS 11
 #endif
 
 namespace {
@@ -108,7 +113,16 @@ __global__ void pack8_kernel(const float *__restrict__ fc0_w, const float *__res
   }
   const float w = ldexpf(W[(size_t)out_ch * H + in_ch], kw);
   const _Float16 hi = (_Float16)w;
-  const _Float16 lo = (_Float16)(w - (float)hi);
+  _Float16 lo = (_Float16)(w - (float)hi);
+#if DEC8_WLO_BITS < 11
+  // experiment (profiles/r03_decoder_ablation.txt): the matrix cores' power depends on the operand bits that toggle;
+  // keep only the top DEC8_WLO_BITS significand bits of the correction fragments (0 = no w_lo at all)
+  {
+    unsigned short b = __builtin_bit_cast(unsigned short, lo);
+    b = DEC8_WLO_BITS == 0 ? (unsigned short)0 : (unsigned short)(b & (0xffffu << (11 - DEC8_WLO_BITS)));
+    lo = __builtin_bit_cast(_Float16, b);
+  }
+#endif
   packed[e] = s == 0 ? hi : lo;
 }
 

@@ -27,7 +27,42 @@ def collect(d, counter, kernel_substr):
     return tot, n
 
 
+def collect_rows(d, counter, kernel_substr):
+    """per-dispatch values in dispatch order"""
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                    rows.append((int(row.get("Dispatch_Id", len(rows))), float(row["Counter_Value"])))
+    return [v for _, v in sorted(rows)]
+
+
+def group_main():
+    """python tools/pmc_traffic.py --group DIR TAG: tools/group_only.py under the two PMC passes (5 launches at B = 32,
+    then 5 at B = 8) -> profiles/group_traffic.json {"32": bytes per launch, "8": ...}"""
+    d, tag = sys.argv[2], sys.argv[3]
+    f = collect_rows(os.path.join(d, "gfetch"), "FETCH_SIZE", "group_lds_kernel")
+    w = collect_rows(os.path.join(d, "gwrite"), "WRITE_SIZE", "group_lds_kernel")
+    assert len(f) == 10 and len(w) == 10, (len(f), len(w))
+    out = {}
+    for B, sl in ((32, slice(1, 5)), (8, slice(6, 10))):          # first launch of each size dropped (cold)
+        fb = sum(f[sl]) / 4 * 1024 * 2                             # KB, gfx950 x2 correction for 16-B/lane streams
+        wb = sum(w[sl]) / 4 * 1024
+        alg = B * ((3 + 128) * 1024 * 32 * 4 + 1024 * 32 * 4 + 128 * 2048 * 4 + 2048 * 12 + 1024 * 12)
+        out[str(B)] = {"bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "algorithmic_bytes": alg}
+        print("group_lds_kernel B=%2d: FETCH_SIZE %.1f MB (x2 corrected) + WRITE_SIZE %.1f MB = %.1f MB per launch; "
+              "algorithmic %.1f MB (ratio %.2f)" % (B, fb / 1e6, wb / 1e6, (fb + wb) / 1e6, alg / 1e6, (fb + wb) / alg))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out["source"] = ("profiles/%s_group_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over "
+                     "tools/group_only.py; FETCH x2 gfx950 correction)" % tag)
+    with open(os.path.join(root, "profiles", "group_traffic.json"), "w") as fh:
+        json.dump(out, fh)
+
+
 def main():
+    if sys.argv[1] == "--group":
+        return group_main()
     d, n_points = sys.argv[1], float(sys.argv[2])
     tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
     kern = "occ_decode"
