@@ -110,3 +110,39 @@ for scale in (1.0, 3.0):
     print('code scale', scale, 'logit range', ex.abs().max().item())
     for m in ('x3','fp8lo','fp8lo_fixed','fp8both','fp8both_fixed'):
         print('  ', m, (run(m)-ex).abs().max().item())
+
+
+# ---- round 3, second question: how many significand bits do the CORRECTION operands need?  (profiles/r03_decoder_ablation.txt:
+# the decoder is power-bound and the matrix cores' power depends on the operand bits that toggle; zeroing the low bits of
+# w_lo costs nothing at run time)
+def trunc_bits(x, bits, nearest):
+    if bits >= 11:
+        return x
+    m, e = torch.frexp(x)                      # x = m 2^e, 0.5 <= |m| < 1
+    s = 2.0 ** bits
+    q = torch.round(m * s) / s if nearest else torch.trunc(m * s) / s
+    return torch.ldexp(q, e)
+
+
+def mm_bits(wb, ab):
+    def f(W, a, mode, kw, ka=6):
+        Ws = W * 2.0**kw; As = a * 2.0**ka
+        whi = f16(Ws); wlo = trunc_bits(f16(Ws - whi), wb, True)
+        ahi = f16_rtz(As); alo = trunc_bits(f16_rtz(As - ahi), ab, False)
+        prod = lambda w_, a_: torch.einsum('nk,bkt->bnt', w_, a_)
+        r = prod(whi, ahi) + prod(whi, alo) + prod(wlo, ahi)
+        return r.float().double() / 2.0**(kw+ka)
+    return f
+
+
+if __name__ == "__main__":
+    print("significand bits kept in w_lo (rounded at pack time) / a_lo (truncated in the kernel): max |dlogit| vs exact")
+    for scale in (1.0, 3.0):
+        c = torch.from_numpy(fx['c']).double() * scale
+        mm = _mm
+        ex = run('exact')
+        row = []
+        for wb, ab in ((11, 11), (9, 11), (8, 11), (7, 11), (6, 11), (8, 8), (7, 7), (6, 6), (5, 5), (4, 4)):
+            mm = mm_bits(wb, ab)
+            row.append("w%d/a%d %.2e" % (wb, ab, (run('x3') - ex).abs().max().item()))
+        print("  code scale %.0f (|logit| <= %.1f): %s" % (scale, ex.abs().max().item(), "  ".join(row)))
