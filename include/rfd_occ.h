@@ -221,6 +221,21 @@ int rfd_pos_embed(int M, int N, int d, const float *x, int ldx, const float *mas
                   const float *W, int ldw, const float *bias, const float *group,
                   int rows_per_group, float *out, int ldo, int sa, void *stream);
 
+/* ---- PointNet feature chains of the skip-propagation nets, fused (csrc/pointseg_chain.hip) ----------------
+ * models/iscnet/modules/pointseg.py:7-42 (STN3d), :45-79 (STNkd), :82-129 (PointNetEncoder): per point
+ *   [d_in -> 64, ReLU] -> 64 -> 128, ReLU -> 128 -> 1024 [, ReLU] -> max over the P points of a proposal
+ * with the BatchNorms folded into W / b by the caller.  mode 1: first layer on d_in <= 8 input columns (STN3d);
+ * mode 2: first layer 64 -> 64 (STNkd); mode 0: no first layer, x is the 64-wide point feature (encoder conv2/3).
+ * rfd_chain_pack splits the weights (scaled by 2^sw, |w| 2^sw <= 2^14) into f16 (hi, lo) MFMA fragments:
+ * rfd_chain_packed_bytes() bytes.  rfd_chain_pool: x [M][ldx] fp32 rows, P % 512 == 0, M % P == 0,
+ * out [M / P][1024].  sa = activation scale exponent (status bit 4 when |activation| 2^sa leaves the f16 range). */
+size_t rfd_chain_packed_bytes(void);
+int rfd_chain_pack(int mode, const float *W1, const float *W2, const float *W3, int sw1, int sw2, int sw3,
+                   void *packed, void *stream);
+int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int ldx, const void *packed,
+                   const float *W1raw, const float *b1, const float *b2, const float *b3, int relu3, int sa,
+                   int sw1, int sw2, int sw3, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,8 @@ SIGNATURES = {
     "rfd_mc_classify": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f],
     "rfd_mc_emit": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f, _f, _f, _f],
     "rfd_mc_blocks": [_i],
+    "rfd_chain_pack": [_i, _f, _f, _f, _i, _i, _i, _f, _f],
+    "rfd_chain_pool": [_i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f],
     "rfd_pos_embed": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _f],
 }
 _RESTYPES = {
@@ -59,7 +61,7 @@ _RESTYPES = {
     "rfd_occ_packed_bytes": C.c_size_t,
 }
 _INT_FNS = {"rfd_stream_status": [_f]}
-_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i]}
+_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_chain_packed_bytes": []}
 
 _lib = None
 

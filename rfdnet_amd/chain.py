@@ -1,0 +1,69 @@
+"""The PointNet feature chains of the skip-propagation nets as one kernel each (csrc/pointseg_chain.hip):
+[d -> 64, ReLU] -> 64 -> 128, ReLU -> 128 -> 1024 [, ReLU] -> max over the P points of a proposal, on the split-f16
+matrix-core arithmetic of gemm.py (fp32-class).  Weights are (W (N,K), b (N)) with BatchNorm already folded in
+(fold_bn.folded); they are split / re-laid once and cached per parameter version."""
+import os
+
+import torch
+
+from . import _lib, gemm, occ_fold
+
+_cache = {}
+
+
+def usable(x, P, d_in):
+    """x (M, d) fp32 CUDA rows, P points per proposal."""
+    M = x.shape[0]
+    if os.environ.get("RFD_NO_CHAIN") == "1":           # A/B timing against the GEMM-per-layer path
+        return False
+    ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and P % 512 == 0 and M % P == 0)
+    if d_in <= 8:
+        return ok
+    return ok and d_in == 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+
+
+def _packed(mode, layers):
+    (W1, _), (W2, _), (W3, _) = layers
+    key = tuple((None if w is None else (w.data_ptr(), w._version, tuple(w.shape))) for w in (W1, W2, W3)) + (mode,)
+    hit = _cache.get(key)
+    if hit is None:
+        assert tuple(W2.shape) == (128, 64) and tuple(W3.shape) == (1024, 128), (W2.shape, W3.shape)
+        sw1 = occ_fold.choose_kw([W1]) if mode == 2 else 0
+        sw2, sw3 = occ_fold.choose_kw([W2]), occ_fold.choose_kw([W3])
+        buf = torch.empty(_lib.lib().rfd_chain_packed_bytes(), dtype=torch.uint8, device=W2.device)
+        w1c = W1.contiguous() if mode == 2 else None
+        w2c, w3c = W2.contiguous(), W3.contiguous()
+        with torch.cuda.device(W2.device):
+            rc = _lib.lib().rfd_chain_pack(mode, w1c.data_ptr() if w1c is not None else None, w2c.data_ptr(),
+                                           w3c.data_ptr(), sw1, sw2, sw3, buf.data_ptr(), _lib.current_stream())
+        _lib.check(rc, "rfd_chain_pack")
+        torch.cuda.current_stream(W2.device).synchronize()          # w?c may be temporaries
+        hit = (buf, sw1, sw2, sw3, (W1, W2, W3))                     # keep the keyed tensors alive
+        if len(_cache) > 64:
+            _cache.clear()
+        _cache[key] = hit
+    return hit
+
+
+def chain_pool(x, layer1, layer2, layer3, P, relu3):
+    """x (M, d); layer1 = (W1 (64,d), b1) or None (x is already the 64-wide feature); layer2 = (W2 (128,64), b2);
+    layer3 = (W3 (1024,128), b3) -> (M / P, 1024) = max over each proposal's points of the chain's output."""
+    M, d = x.shape
+    if layer1 is None:
+        mode, layer1 = 0, (None, None)
+    else:
+        mode = 1 if d <= 8 else 2
+        assert tuple(layer1[0].shape) == (64, d), layer1[0].shape
+    assert usable(x, P, d)
+    buf, sw1, sw2, sw3, _ = _packed(mode, (layer1, layer2, layer3))
+    out = torch.empty(M // P, 1024, dtype=torch.float32, device=x.device)
+    w1raw = layer1[0].contiguous() if mode == 1 else None
+    b1 = layer1[1].contiguous() if mode else None
+    b2, b3 = layer2[1].contiguous(), layer3[1].contiguous()
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().rfd_chain_pool(mode, M, P, d, x.data_ptr(), x.stride(0), buf.data_ptr(),
+                                       w1raw.data_ptr() if w1raw is not None else None,
+                                       b1.data_ptr() if b1 is not None else None, b2.data_ptr(), b3.data_ptr(),
+                                       int(bool(relu3)), gemm.SA, sw1, sw2, sw3, out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "rfd_chain_pool")
+    return out

@@ -1,0 +1,364 @@
+// pointseg_chain.hip -- the three PointNet feature chains of the skip-propagation PointSeg / STN nets, each as ONE kernel:
+//     x (M, d)  ->  [d -> 64]  ->  64 -> 128  ->  128 -> 1024  ->  max over the P points of a proposal
+// (models/iscnet/modules/pointseg.py:7-42 STN3d, :45-79 STNkd, :82-129 PointNetEncoder: conv1/conv2/conv3 + folded
+// BatchNorm + ReLU, torch.max(x, 2)).  Before: per chain two or three GEMM launches writing / re-reading the 64- and
+// 128-wide intermediates (200 MB each way) and a 128 -> 1024 pool-only GEMM whose max over the points was a cross-lane
+// reduction of every accumulator register (190 TFLOP/s).  Here the intermediates stay in registers (the accumulator
+// layout of one layer is the B-fragment layout of the next, as in the occupancy decoder) and the last layer is issued
+// with the operands swapped -- A = activations, B = weights -- so an accumulator holds ONE output channel per lane and
+// four POINTS per register: the max over the points is 15 v_max per lane and two lane exchanges per 16-channel tile.
+//
+// Arithmetic = the split-precision GEMM's (csrc/gemm_f16x3.hip): f16 (hi, lo) splits of both operands, three
+// v_mfma_f32_16x16x32_f16 per product, fp32 accumulate, activations scaled by 2^sa, weights by 2^sw (exact).
+// One workgroup = one proposal (P = 1024 points): a wave owns P/8 points, 64 at a time (four 16-point groups share every
+// weight fragment read); the 128 -> 1024 weights (512 KiB of fragments) stream through a 3-slot LDS ring by LDS-DMA,
+// the two small layers' weights sit in LDS for the kernel's lifetime.  MODE: 1 = first layer d <= 8 on the VALU (STN3d),
+// 2 = first layer 64 -> 64 on the matrix cores (STNkd), 0 = no first layer (PointNetEncoder conv2 / conv3).
+#include "common.h"
+#include "../../include/rfd_occ.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int C1 = 64, C2 = 128, C3 = 1024;
+constexpr int PIECE = 32 * 1024;                       // 4 output tiles of the last layer x (4 k-steps x hi, lo) x 1 KiB
+constexpr int N_PIECES = C3 / 16 / 4;                  // 16
+constexpr int W3_BYTES = N_PIECES * PIECE;             // 512 KiB
+constexpr int W2_BYTES = (C2 / 16) * 2 * 2 * 1024;     // 8 tiles x 2 k-steps x (hi, lo): 32 KiB
+constexpr int W1_BYTES = (C1 / 16) * 2 * 2 * 1024;     // 4 tiles x 2 k-steps x (hi, lo): 16 KiB
+constexpr int OFF_W2 = 3 * PIECE, OFF_W1 = OFF_W2 + W2_BYTES, OFF_B = OFF_W1 + W1_BYTES;
+constexpr int B_FLOATS = C1 + C2 + C3 + C1 * 8 + C3;   // b1, b2, b3, raw W1 (64 x 8), pooled maxima
+constexpr int SMEM = OFF_B + B_FLOATS * 4;             // 154 368 B
+
+__device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// k order of a 32-wide k-step whose operand is a previous layer's accumulators: lane group kg, slot j
+__host__ __device__ inline int chain_k(int ks, int kg, int j) { return 32 * ks + 16 * (j >> 2) + 4 * kg + (j & 3); }
+
+// packed = [W3 stream 512 KiB][W2 32 KiB][W1 16 KiB]; every fragment = 64 lanes x 8 halves
+__global__ void chain_pack_kernel(int mode, const float *__restrict__ W1, const float *__restrict__ W2,
+                                  const float *__restrict__ W3, int sw1, int sw2, int sw3, _Float16 *__restrict__ packed) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)(W3_BYTES + W2_BYTES + W1_BYTES) / 2;
+  if (e >= total) return;
+  const int j = e & 7, lane = (e >> 3) & 63, idx = lane & 15, kg = lane >> 4;
+  size_t frag = e >> 9;
+  float w;
+  int split;
+  if (frag < (size_t)W3_BYTES / 1024) {                 // B operand of the last layer: column idx = output channel
+    split = frag & 1;
+    const int ks = (frag >> 1) & 3, tile = (int)(frag >> 3);
+    w = ldexpf(W3[(size_t)(16 * tile + idx) * C2 + chain_k(ks, kg, j)], sw3);
+  } else if ((frag -= W3_BYTES / 1024) < (size_t)W2_BYTES / 1024) {   // A operand: row idx = output channel
+    split = frag & 1;
+    const int ks = (frag >> 1) & 1, tile = (int)(frag >> 2);
+    const int k = mode == 0 ? 32 * ks + 8 * kg + j : chain_k(ks, kg, j);   // input straight from memory: natural order
+    w = ldexpf(W2[(size_t)(16 * tile + idx) * C1 + k], sw2);
+  } else {
+    frag -= W2_BYTES / 1024;
+    split = frag & 1;
+    const int ks = (frag >> 1) & 1, tile = (int)(frag >> 2);
+    w = mode == 2 ? ldexpf(W1[(size_t)(16 * tile + idx) * C1 + 32 * ks + 8 * kg + j], sw1) : 0.f;
+  }
+  const _Float16 hi = (_Float16)w;
+  const _Float16 lo = (_Float16)(w - (float)hi);
+  packed[e] = split == 0 ? hi : lo;
+}
+
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// two scaled values -> packed f16 hi (round to zero) and lo words
+__device__ __forceinline__ void split2(float a0, float a1, unsigned &hiw, unsigned &low, unsigned &amax16) {
+  hiw = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+  amax16 = pk_max_u16(amax16, hiw & 0x7fff7fffu);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hiw), "v"(a0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hiw), "v"(a1));
+  low = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+}
+
+// accumulators of channel tiles 2ks, 2ks+1 (+ bias, ReLU, scale) -> the next layer's operand fragment pair of k-step ks
+__device__ __forceinline__ void act_pair(const f32x4 &x0, const f32x4 &x1, const float *bias, int ch, float oscale,
+                                         float ascale, half8 &hi, half8 &lo, unsigned &amax16) {
+  const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias + ch), b1 = *reinterpret_cast<const f32x4 *>(bias + ch + 16);
+  float v[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float a = __builtin_fmaf(x0[r], oscale, b0[r]), c = __builtin_fmaf(x1[r], oscale, b1[r]);
+    v[r] = (a > 0.f ? a : 0.f) * ascale;
+    v[4 + r] = (c > 0.f ? c : 0.f) * ascale;
+  }
+  unsigned hw[4], lw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split2(v[2 * q], v[2 * q + 1], hw[q], lw[q], amax16);
+  hi = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+  lo = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+}
+
+struct ChainArgs {
+  int M, P, d_in, ldx, relu3;
+  const float *x;
+  const half8 *packed;
+  const float *W1raw, *b1, *b2, *b3;
+  float ascale, os1, os2, os3;      // 2^sa, 2^-(sa+sw1), 2^-(sa+sw2), 2^-(sa+sw3)
+  float *out;
+  unsigned *status;
+};
+
+__device__ __forceinline__ void pool_lds(float *p, float v) {          // running max in LDS, any sign (initialised to -inf)
+  if (v >= 0.f) atomicMax(reinterpret_cast<int *>(p), __float_as_int(v + 0.f));
+  else atomicMin(reinterpret_cast<unsigned *>(p), __float_as_uint(v));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void chain_kernel(ChainArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  float *s_b1 = reinterpret_cast<float *>(smem + OFF_B), *s_b2 = s_b1 + C1, *s_b3 = s_b2 + C2;
+  float *s_w1 = s_b3 + C3, *s_red = s_w1 + C1 * 8;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
+  const int prop = blockIdx.x;
+  const char *gp = reinterpret_cast<const char *>(a.packed);
+  unsigned amax16 = 0u;
+
+  // ---- per-workgroup constants: the two small layers' fragments, biases, pooled maxima
+  {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(gp + W3_BYTES);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(smem + OFF_W2);
+    for (int i = t; i < (W2_BYTES + (MODE == 2 ? W1_BYTES : 0)) / 16; i += 512) dst[i] = src[i];
+    for (int i = t; i < C1; i += 512) s_b1[i] = MODE ? a.b1[i] : 0.f;
+    for (int i = t; i < C2; i += 512) s_b2[i] = a.b2[i];
+    for (int i = t; i < C3; i += 512) {
+      s_b3[i] = a.b3[i];
+      s_red[i] = -__builtin_inff();
+    }
+    if (MODE == 1)
+      for (int i = t; i < C1 * 8; i += 512) s_w1[i] = (i & 7) < a.d_in ? a.W1raw[(i >> 3) * a.d_in + (i & 7)] : 0.f;
+  }
+  const int pts_per_wave = a.P / 8, passes = pts_per_wave / 64, total_pieces = passes * N_PIECES;
+  auto dma_piece = [&](int p) {          // wave w moves fragments 4w .. 4w+3 of piece p (32 fragments)
+    const char *src = gp + (size_t)(p % N_PIECES) * PIECE + (wave * 4) * 1024 + lane * 16;
+    unsigned char *dst = smem + (p % 3) * PIECE + (wave * 4) * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + q * 1024), (lds_void *)(dst + q * 1024), 16, 0, 0);
+  };
+  dma_piece(0);
+  dma_piece(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const half8 *w2 = reinterpret_cast<const half8 *>(smem + OFF_W2) + lane;
+  const half8 *w1 = reinterpret_cast<const half8 *>(smem + OFF_W1) + lane;
+  for (int pass = 0; pass < passes; ++pass) {
+    const size_t row0 = (size_t)prop * a.P + (size_t)wave * pts_per_wave + (size_t)pass * 64;
+    half8 h2hi[4][4], h2lo[4][4];                                     // [group][k-step]: the last layer's A operands
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+      const float *xr = a.x + (row0 + 16 * grp + n) * (size_t)a.ldx;
+      half8 h1hi[2], h1lo[2];
+      if (MODE == 1) {
+        // first layer on the VALU, in the accumulator layout: lane (point n, g) computes channels 16 tt + 4 g + r
+        float xin[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xin[j] = j < a.d_in ? xr[j] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int ch = 32 * ks + 16 * (q >> 2) + g4 + (q & 3);
+            float acc = s_b1[ch];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_fmaf(s_w1[ch * 8 + j], xin[j], acc);
+            v[q] = (acc > 0.f ? acc : 0.f) * a.ascale;
+          }
+          unsigned hw[4], lw[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) split2(v[2 * q], v[2 * q + 1], hw[q], lw[q], amax16);
+          h1hi[ks] = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+          h1lo[ks] = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+        }
+      } else {
+        // 64 input channels from memory as fragments in their natural k order: lane (n, g) holds k = 32 ks + 8 g + j
+        half8 inhi[2], inlo[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const f32x4 u0 = *reinterpret_cast<const f32x4 *>(xr + 32 * ks + 8 * g);
+          const f32x4 u1 = *reinterpret_cast<const f32x4 *>(xr + 32 * ks + 8 * g + 4);
+          unsigned hw[4], lw[4];
+          split2(u0[0] * a.ascale, u0[1] * a.ascale, hw[0], lw[0], amax16);
+          split2(u0[2] * a.ascale, u0[3] * a.ascale, hw[1], lw[1], amax16);
+          split2(u1[0] * a.ascale, u1[1] * a.ascale, hw[2], lw[2], amax16);
+          split2(u1[2] * a.ascale, u1[3] * a.ascale, hw[3], lw[3], amax16);
+          inhi[ks] = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+          inlo[ks] = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+        }
+        if (MODE == 2) {
+          f32x4 d1[4];
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const half8 wh = w1[((tt * 2 + ks) * 2) * 64], wl = w1[((tt * 2 + ks) * 2 + 1) * 64];
+              acc = mfma16(wh, inhi[ks], acc);
+              acc = mfma16(wh, inlo[ks], acc);
+              acc = mfma16(wl, inhi[ks], acc);
+            }
+            d1[tt] = acc;
+          }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            act_pair(d1[2 * ks], d1[2 * ks + 1], s_b1, 32 * ks + g4, a.os1, a.ascale, h1hi[ks], h1lo[ks], amax16);
+        } else {
+          h1hi[0] = inhi[0]; h1hi[1] = inhi[1];
+          h1lo[0] = inlo[0]; h1lo[1] = inlo[1];
+        }
+      }
+      // ---- 64 -> 128
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 d2[8];
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const half8 wh = w2[((tt * 2 + ks) * 2) * 64], wl = w2[((tt * 2 + ks) * 2 + 1) * 64];
+          acc = mfma16(wh, h1hi[ks], acc);
+          acc = mfma16(wh, h1lo[ks], acc);
+          acc = mfma16(wl, h1hi[ks], acc);
+        }
+        d2[tt] = acc;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        act_pair(d2[2 * ks], d2[2 * ks + 1], s_b2, 32 * ks + g4, a.os2, a.ascale, h2hi[grp][ks], h2lo[grp][ks], amax16);
+      __builtin_amdgcn_sched_barrier(0);      // one group at a time: four interleaved groups do not fit the register file
+    }
+
+    // ---- 128 -> 1024 with the operands swapped (A = activations, B = weights) + max over the wave's 64 points
+    for (int i = 0; i < N_PIECES; ++i) {
+      const int p = pass * N_PIECES + i;
+      if (p + 2 < total_pieces) dma_piece(p + 2);
+      const half8 *w3 = reinterpret_cast<const half8 *>(smem + (p % 3) * PIECE) + lane;
+      // fragments of a tile: 4 k-steps x (hi, lo); the next tile's are fetched under this tile's 48 MFMAs into the OTHER
+      // register set (the set in use is kept allocated to the end of the tile, nothing is scheduled across tiles: same
+      // discipline as the decoder's prefetch, csrc/occ_decoder8.hip)
+      half8 cw[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cw[q] = w3[q * 64];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        __builtin_amdgcn_sched_barrier(0);
+        half8 nw[8];
+        if (tt < 3) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) nw[q] = w3[((tt + 1) * 8 + q) * 64];
+        }
+        f32x4 d[4];
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) d[grp] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int grp = 0; grp < 4; ++grp) {
+            d[grp] = mfma16(h2hi[grp][ks], cw[2 * ks], d[grp]);
+            d[grp] = mfma16(h2lo[grp][ks], cw[2 * ks], d[grp]);
+            d[grp] = mfma16(h2hi[grp][ks], cw[2 * ks + 1], d[grp]);
+          }
+        // lane (n = output channel, g): d[grp][r] = point 16 grp + 4 g + r
+        float m = d[0][0];
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = d[grp][r] > m ? d[grp][r] : m;
+        float o = __shfl_xor(m, 16);
+        m = o > m ? o : m;
+        o = __shfl_xor(m, 32);
+        m = o > m ? o : m;
+        if (lane < 16) pool_lds(s_red + 16 * (4 * i + tt) + n, m);
+        asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]), "v"(cw[7]));
+        if (tt < 3) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) cw[q] = nw[q];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the piece after this one must have landed (this wave's four transfers of piece p + 2 may still fly)
+      if (p + 2 < total_pieces) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  // ---- out[prop][c] = relu?(max * 2^-(sa+sw3) + b3[c])   (max commutes with the positive scale, the bias and the ReLU)
+  for (int c = t; c < C3; c += 512) {
+    float o = __builtin_fmaf(s_red[c], a.os3, s_b3[c]);
+    if (a.relu3) o = o > 0.f ? o : 0.f;
+    a.out[(size_t)prop * C3 + c] = o;
+  }
+  if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(a.status, 4u);
+}
+
+}  // namespace
+
+RFD_API size_t rfd_chain_packed_bytes(void) { return (size_t)W3_BYTES + W2_BYTES + W1_BYTES; }
+
+// W1 [64][64] (mode 2) or NULL, W2 [128][64], W3 [1024][128]: fp32, BatchNorm already folded in by the caller.
+RFD_API int rfd_chain_pack(int mode, const float *W1, const float *W2, const float *W3, int sw1, int sw2, int sw3,
+                           void *packed, void *stream) {
+  if (mode < 0 || mode > 2 || !W2 || !W3 || (mode == 2 && !W1)) {
+    rfd_set_error("rfd_chain_pack: mode / weights", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  const size_t total = rfd_chain_packed_bytes() / 2;
+  hipLaunchKernelGGL(chain_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mode,
+                     W1, W2, W3, sw1, sw2, sw3, (_Float16 *)packed);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+// x [M][ldx] fp32 rows (d_in <= 8 columns used in mode 1, 64 otherwise; 16-byte aligned rows for modes 0 / 2),
+// P points per proposal (P % 512 == 0: 8 waves x 64 points), out [M / P][1024].
+RFD_API int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int ldx, const void *packed,
+                           const float *W1raw, const float *b1, const float *b2, const float *b3, int relu3, int sa,
+                           int sw1, int sw2, int sw3, float *out, void *stream) {
+  if (M <= 0) return 0;
+  if (mode < 0 || mode > 2 || P <= 0 || P % 512 || M % P || (mode == 1 && (d_in < 1 || d_in > 8 || !W1raw)) ||
+      (mode != 1 && (d_in != 64 || (ldx & 3) || ((uintptr_t)x & 15))) || (mode && !b1) || !b2 || !b3 || !out) {
+    rfd_set_error("rfd_chain_pool: need P % 512 == 0, M % P == 0, d_in <= 8 (mode 1) or 64 with 16-byte rows",
+                  hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  RfdWorkspace *ws;
+  {
+    int rc = rfd_get_workspace(&ws);
+    if (rc) return rc;
+  }
+  ChainArgs a;
+  a.M = M; a.P = P; a.d_in = d_in; a.ldx = ldx; a.relu3 = relu3; a.x = x; a.packed = (const half8 *)packed;
+  a.W1raw = W1raw; a.b1 = b1; a.b2 = b2; a.b3 = b3;
+  a.ascale = ldexpf(1.f, sa); a.os1 = ldexpf(1.f, -(sa + sw1)); a.os2 = ldexpf(1.f, -(sa + sw2));
+  a.os3 = ldexpf(1.f, -(sa + sw3));
+  a.out = out;
+  a.status = rfd_status_word(ws, (hipStream_t)stream);
+  const dim3 grid(M / P), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) hipLaunchKernelGGL(chain_kernel<0>, grid, block, 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL(chain_kernel<1>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(chain_kernel<2>, grid, block, 0, s, a);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}

@@ -42,9 +42,15 @@ class _TNet(nn.Module):
         """Row-major inference path: x (B*P, k_in) -> (B, k_out, k_out).  BN folded,
         the wide layers on the split-precision GEMM with fused bias + ReLU."""
         from ..fold_bn import folded, linear_rows, linear_rows_pooled
-        h = linear_rows(x, *folded(self.conv1, self.bn1), relu=True)
-        h = linear_rows(h, *folded(self.conv2, self.bn2), relu=True)
-        g = linear_rows_pooled(h, *folded(self.conv3, self.bn3), rows_per_group=P)    # relu + max over the points
+        from .. import chain
+        if chain.usable(x, P, x.shape[1]) and x.shape[1] in (64,) + tuple(range(1, 9)):
+            # the whole conv1 -> conv2 -> conv3 -> max chain in one kernel (csrc/pointseg_chain.hip)
+            g = chain.chain_pool(x, folded(self.conv1, self.bn1), folded(self.conv2, self.bn2),
+                                 folded(self.conv3, self.bn3), P, relu3=True)
+        else:
+            h = linear_rows(x, *folded(self.conv1, self.bn1), relu=True)
+            h = linear_rows(h, *folded(self.conv2, self.bn2), relu=True)
+            g = linear_rows_pooled(h, *folded(self.conv3, self.bn3), rows_per_group=P)    # relu + max over the points
         g = linear_rows(g, *folded(self.fc1, self.bn4), relu=True)
         g = linear_rows(g, *folded(self.fc2, self.bn5), relu=True)
         g = F.linear(g, self.fc3.weight, self.fc3.bias)
@@ -166,8 +172,12 @@ class PointSeg(nn.Module):
             trans_feat = enc.fstn.forward_rows(h, P)                         # (B,64,64)
             h = torch.bmm(h.view(B, P, -1), trans_feat).reshape(B * P, -1)
         pointfeat = h
-        h = linear_rows(pointfeat, *folded(enc.conv2, enc.bn2), relu=True)
-        g = linear_rows_pooled(h, *folded(enc.conv3, enc.bn3), P, relu=False)   # (B,1024), product never written
+        from .. import chain
+        if chain.usable(pointfeat, P, pointfeat.shape[1]) and pointfeat.shape[1] == 64:
+            g = chain.chain_pool(pointfeat, None, folded(enc.conv2, enc.bn2), folded(enc.conv3, enc.bn3), P, relu3=False)
+        else:
+            h = linear_rows(pointfeat, *folded(enc.conv2, enc.bn2), relu=True)
+            g = linear_rows_pooled(h, *folded(enc.conv3, enc.bn3), P, relu=False)   # (B,1024), product never written
         # head conv1 on cat([global (1024, per proposal), pointfeat (64, per point)]) + bn1
         W, b = folded(self.conv1, self.bn1)
         c = self.__dict__.get('_head_split')

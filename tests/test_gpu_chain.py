@@ -1,0 +1,85 @@
+"""GPU (-m gpu): the fused PointNet feature chains (csrc/pointseg_chain.hip) against an fp64 composition of the same
+layers -- [d -> 64, ReLU] -> 64 -> 128, ReLU -> 128 -> 1024 [, ReLU] -> max over each proposal's points
+(models/iscnet/modules/pointseg.py:7-42, :45-79, :82-129 with the BatchNorms folded).  fp32-class accuracy is the
+contract (the layers it replaces ran on the split-precision GEMM / fp32 library GEMMs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def reference(x, l1, l2, l3, P, relu3):
+    h = x.double()
+    if l1 is not None:
+        h = torch.relu(h @ l1[0].double().t() + l1[1].double())
+    h = torch.relu(h @ l2[0].double().t() + l2[1].double())
+    h = h @ l3[0].double().t() + l3[1].double()
+    if relu3:
+        h = torch.relu(h)
+    return h.view(-1, P, 1024).max(dim=1)[0]
+
+
+def layers(g, d):
+    def lin(n, k, scale):
+        return ((torch.rand(n, k, device="cuda", generator=g) * 2 - 1) * scale / np.sqrt(k),
+                torch.randn(n, device="cuda", generator=g) * 0.3)
+    return (lin(64, d, 2.0) if d else None), lin(128, 64, 2.0), lin(1024, 128, 2.0)
+
+
+@pytest.mark.parametrize("mode,d,relu3,B,P", [(1, 4, True, 3, 1024), (1, 3, True, 2, 512), (1, 7, True, 1, 1024),
+                                               (2, 64, True, 3, 1024), (0, 0, False, 5, 1024), (0, 0, True, 2, 1536)])
+def test_chain_matches_fp64_composition(hip, mode, d, relu3, B, P):
+    from rfdnet_amd import chain
+    g = torch.Generator(device="cuda").manual_seed(10 * mode + d)
+    l1, l2, l3 = layers(g, d)
+    if not relu3:
+        l3 = (l3[0], l3[1] - 3.0)                       # negative maxima too: the pool keeps the sign
+    din = d if mode else 64
+    x = torch.randn(B * P, din, device="cuda", generator=g) * 1.5
+    if mode == 1:                                        # a strided view like inp.reshape(B * P, D) of a wider buffer
+        wide = torch.zeros(B * P, din + 3, device="cuda")
+        wide[:, :din] = x
+        x = wide[:, :din]
+    assert chain.usable(x, P, din)
+    out = chain.chain_pool(x, l1, l2, l3, P, relu3)
+    hip.device_status()
+    ref = reference(x, l1, l2, l3, P, relu3)
+    err = (out.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    print("mode %d d %d P %d: max |out - fp64| / max(1, |ref|) = %.2e (|ref| up to %.2f, min %.2f)"
+          % (mode, din, P, err, ref.abs().max().item(), ref.min().item()))
+    assert out.shape == (B, 1024)
+    if not relu3:
+        assert (ref < 0).any()
+    assert err < 2e-5
+
+
+def test_chain_is_what_the_layerwise_path_computes(hip, monkeypatch):
+    """PointSeg.forward_rows with the fused chains against the same module with RFD_NO_CHAIN=1 (one GEMM per layer)."""
+    from rfdnet_amd import synthetic
+    from rfdnet_amd.iscnet.pointseg import PointSeg
+    seg = PointSeg(2, 4)
+    synthetic.load_seeded(seg, 7)
+    seg = seg.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    inp = torch.randn(6, 1024, 4, device="cuda", generator=g)
+    with torch.no_grad():
+        a, ta = seg.forward_rows(inp)
+        monkeypatch.setenv("RFD_NO_CHAIN", "1")
+        b, tb = seg.forward_rows(inp)
+    hip.device_status()
+    d = (a - b).abs().max().item()
+    dt = (ta - tb).abs().max().item()
+    print("log-probabilities: max |fused - layerwise| = %.2e; feature transform: %.2e" % (d, dt))
+    assert d < 1e-4 and dt < 1e-4
+
+
+def test_chain_flags_activations_beyond_the_f16_range(hip):
+    from rfdnet_amd import chain
+    g = torch.Generator(device="cuda").manual_seed(1)
+    l1, l2, l3 = layers(g, 4)
+    x = torch.randn(1024, 4, device="cuda", generator=g)
+    x[5, 0] = 1.0e5                                      # first-layer output ~1e5: * 2^4 leaves the f16 range
+    chain.chain_pool(x, l1, l2, l3, 1024, True)
+    with pytest.raises(hip.RfdHipError, match="split-precision GEMM"):
+        hip.device_status()
