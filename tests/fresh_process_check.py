@@ -6,7 +6,7 @@ failure mode (a register read before its hand-issued load has landed shows up on
 caches / first-touch page faults).
 
   kernels: gemm_rows8 (row-owner split-precision GEMM, with and without fused pooling),
-           the tile GEMM, occ_decode (4 waves), occ_decode8 (8 waves), sa_fused.
+           the tile GEMM, occ_decode (4 waves), occ_decode8 (8 waves), sa_fused, the fused PointNet chains.
 """
 import os
 import sys
@@ -111,6 +111,35 @@ def check_decoder_stress():
     return e
 
 
+def check_chain(seed):
+    """the fused PointNet feature chains (csrc/pointseg_chain.hip: LDS-DMA weight ring, hand-counted vmcnt waits)
+    from a cold context, all three modes, twice each: bit-identical runs and fp32-class agreement with fp64"""
+    from rfdnet_amd import chain
+    g = torch.Generator(device="cuda").manual_seed(100 + seed)
+
+    def lin(n, k):
+        return ((torch.rand(n, k, device="cuda", generator=g) * 2 - 1) * 2.0 / np.sqrt(k),
+                torch.randn(n, device="cuda", generator=g) * 0.3)
+    worst = 0.0
+    for d, relu3 in ((4, True), (64, True), (0, False)):
+        l1 = lin(64, d) if d else None
+        l2, l3 = lin(128, 64), lin(1024, 128)
+        x = torch.randn(3 * 1024, d if d else 64, device="cuda", generator=g)
+        a = chain.chain_pool(x, l1, l2, l3, 1024, relu3)
+        b = chain.chain_pool(x, l1, l2, l3, 1024, relu3)
+        assert torch.equal(a, b), "fused chain (d=%d): two runs on the same input differ" % d
+        h = x.double()
+        if l1 is not None:
+            h = torch.relu(h @ l1[0].double().t() + l1[1].double())
+        h = torch.relu(h @ l2[0].double().t() + l2[1].double()) @ l3[0].double().t() + l3[1].double()
+        if relu3:
+            h = torch.relu(h)
+        ref = h.view(3, 1024, 1024).max(dim=1)[0]
+        worst = max(worst, (a.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
+    assert worst < 2e-5, "fused chain off by %.3g (relative)" % worst
+    return worst
+
+
 def check_sa_fused(seed):
     from rfdnet_amd import sa_fused
     from rfdnet_amd.pointnet2_ops.pointnet2_modules import PointnetSAModuleVotes
@@ -139,8 +168,8 @@ def main():
     assert torch.cuda.is_available()
     # cold start on purpose: the kernels under test are the FIRST launches of this context
     order = [lambda: ("gemm", check_gemm(seed)), lambda: ("decoders", check_decoders()),
-             lambda: ("sa_fused", check_sa_fused(seed))]
-    order = order[seed % 3:] + order[:seed % 3]           # rotate which kernel meets the coldest state
+             lambda: ("sa_fused", check_sa_fused(seed)), lambda: ("chain", check_chain(seed))]
+    order = order[seed % 4:] + order[:seed % 4]           # rotate which kernel meets the coldest state
     if seed % 7 == 3:                                     # seeds 3, 10, 17 of the twenty
         order = [lambda: ("decoder_stress", check_decoder_stress())] + order
     res = [f() for f in order]
