@@ -94,11 +94,14 @@ DECODE_LOCK = threading.Lock()
 
 
 class DecodeTimer(object):
-    """HIP-event timing of every decoder launch on the stream it runs on.  The
-    decoder owns the whole chip (one persistent workgroup per CU), so with several
-    scenes in flight its launches are serialised with a host lock: each launch runs
-    alone w.r.t. other decoder launches and its event-bracketed duration is the
-    kernel's own (the same number rocprofv3's kernel trace reports)."""
+    """HIP-event timing of every decoder launch on the stream it runs on.  The decoder owns the whole chip (one
+    persistent workgroup per CU), so with several scenes in flight its launches execute one after the other anyway;
+    to make each event-bracketed duration the kernel's own, a launch's stream first WAITS (on the device) for the end
+    event of the previous decoder launch of any stream, then records its start event.  No host thread blocks for it
+    (round 2 held a host lock across `e1.synchronize()` inside the timed region); the lock below only covers the
+    enqueue.  Durations are read after the timed region's final synchronisation."""
+
+    last_end = None            # end event of the most recent decoder launch on this device (any stream)
 
     def __init__(self, dec):
         import torch
@@ -111,10 +114,12 @@ class DecodeTimer(object):
             with DECODE_LOCK:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
+                if DecodeTimer.last_end is not None:
+                    torch.cuda.current_stream().wait_event(DecodeTimer.last_end)
                 e0.record()
                 out = self._orig(pts, tile_prop, *a, **k)
                 e1.record()
-                e1.synchronize()
+                DecodeTimer.last_end = e1
             if self.enabled:
                 self.records.append((int(tile_prop.shape[0]) * 128, e0, e1))
             return out
