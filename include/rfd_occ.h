@@ -236,6 +236,18 @@ int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int ldx, co
                    const float *W1raw, const float *b1, const float *b2, const float *b3, int relu3, int sa,
                    int sw1, int sw2, int sw3, float *out, void *stream);
 
+/* PointSeg's per-point head fused (csrc/pointseg_chain.hip; pointseg.py:131-154 with the BatchNorms folded):
+ *   x [M][ldx] (64-wide point feature) -> 64 -> 512 (+ gbias[row / P], ReLU) -> 256 (ReLU) -> 128 (ReLU) -> n_cls scores
+ * gbias [M / P][512] = conv1's bias + its global-feature columns applied to the proposal's global feature (one vector per
+ * proposal, computed by the caller).  Wa [512][64], Wb [256][512], Wc [128][256] packed by rfd_head_pack
+ * (rfd_head_packed_bytes() bytes); Wd [n_cls][128], bd [n_cls] fp32, n_cls <= 2; P % 128 == 0; out [M][n_cls]. */
+size_t rfd_head_packed_bytes(void);
+int rfd_head_pack(const float *Wa, const float *Wb, const float *Wc, int swa, int swb, int swc, void *packed,
+                  void *stream);
+int rfd_head_scores(int M, int P, const float *x, int ldx, const void *packed, const float *gbias, const float *bb,
+                    const float *bc, const float *Wd, const float *bd, int n_cls, int sa, int swa, int swb, int swc,
+                    float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

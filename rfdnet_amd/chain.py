@@ -67,3 +67,47 @@ def chain_pool(x, layer1, layer2, layer3, P, relu3):
                                        int(bool(relu3)), gemm.SA, sw1, sw2, sw3, out.data_ptr(), _lib.current_stream())
     _lib.check(rc, "rfd_chain_pool")
     return out
+
+
+def head_usable(x, P, n_cls):
+    return (os.environ.get("RFD_NO_CHAIN") != "1" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and x.shape[1] == 64 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and P % 128 == 0 and x.shape[0] % P == 0 and 1 <= n_cls <= 2)
+
+
+def _head_packed(Wa, Wb, Wc):
+    key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in (Wa, Wb, Wc)) + ("head",)
+    hit = _cache.get(key)
+    if hit is None:
+        assert tuple(Wa.shape) == (512, 64) and tuple(Wb.shape) == (256, 512) and tuple(Wc.shape) == (128, 256)
+        swa, swb, swc = (occ_fold.choose_kw([w]) for w in (Wa, Wb, Wc))
+        buf = torch.empty(_lib.lib().rfd_head_packed_bytes(), dtype=torch.uint8, device=Wa.device)
+        wa, wb, wc = Wa.contiguous(), Wb.contiguous(), Wc.contiguous()
+        with torch.cuda.device(Wa.device):
+            rc = _lib.lib().rfd_head_pack(wa.data_ptr(), wb.data_ptr(), wc.data_ptr(), swa, swb, swc, buf.data_ptr(),
+                                          _lib.current_stream())
+        _lib.check(rc, "rfd_head_pack")
+        torch.cuda.current_stream(Wa.device).synchronize()
+        hit = (buf, swa, swb, swc, (Wa, Wb, Wc))
+        if len(_cache) > 64:
+            _cache.clear()
+        _cache[key] = hit
+    return hit
+
+
+def head_scores(x, P, Wa, gbias, layer_b, layer_c, Wd, bd):
+    """PointSeg's per-point head in one kernel: x (M,64) point features; Wa (512,64) = conv1's point-feature columns,
+    gbias (M/P,512) = conv1's bias + its global-feature share per proposal; layer_b = (Wb (256,512), bb), layer_c =
+    (Wc (128,256), bc) with BatchNorm folded; Wd (n_cls,128), bd (n_cls,) -> raw class scores (M, n_cls)."""
+    M = x.shape[0]
+    n_cls = Wd.shape[0]
+    assert head_usable(x, P, n_cls) and tuple(gbias.shape) == (M // P, 512)
+    buf, swa, swb, swc, _ = _head_packed(Wa, layer_b[0], layer_c[0])
+    out = torch.empty(M, n_cls, dtype=torch.float32, device=x.device)
+    gb, bb, bc, wd, b_d = (t.contiguous() for t in (gbias, layer_b[1], layer_c[1], Wd, bd))
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().rfd_head_scores(M, P, x.data_ptr(), x.stride(0), buf.data_ptr(), gb.data_ptr(), bb.data_ptr(),
+                                        bc.data_ptr(), wd.data_ptr(), b_d.data_ptr(), n_cls, gemm.SA, swa, swb, swc,
+                                        out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "rfd_head_scores")
+    return out

@@ -312,6 +312,224 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a) {
   if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(a.status, 4u);
 }
 
+// =====================================================================================================================
+// PointSeg's per-point head (pointseg.py:131-154: conv1 1088 -> 512 on cat([global feature, point feature]), conv2
+// 512 -> 256, conv3 256 -> 128, conv4 128 -> k, BatchNorms folded, ReLU between) as ONE kernel.  The 1024 global-feature
+// columns of conv1 are one vector per proposal (gbias, computed by the caller), so per point it is
+//     64 -> 512 (+ gbias[proposal], ReLU) -> 256 (ReLU) -> 128 (ReLU) -> k = 2 scores.
+// Before: four launches writing / re-reading 512-, 256- and 128-wide intermediates of 262 144 rows (1.9 GB).  Here a wave
+// owns 16 points at a time and the layers are interleaved the way the occupancy decoder interleaves fc_0 and fc_1: every
+// 32-channel slab of the 512-wide layer is rectified in registers and consumed at once as one k-step of the 256-wide layer,
+// whose sixteen accumulator tiles are the only wide state (64 registers).  All weights (768 KiB of fragments per pass)
+// stream through a 3-slot LDS ring in consumption order; the last layer (128 -> 2) is fp32 on the VALU.
+constexpr int HA = 512, HB = 256, HC = 128;
+constexpr int HPIECE = 40 * 1024;                 // one slab: 8 fragments of layer a + 32 of layer b (c pieces: 32 + 8 unused)
+constexpr int H_SLABS = HA / 32;                  // 16
+constexpr int H_CPIECES = (HC / 16) * (HB / 32) * 2 / 32;      // 128 fragments of layer c = 4 pieces
+constexpr int H_PIECES = H_SLABS + H_CPIECES;     // 20 per pass
+constexpr int H_OFF_T = 3 * HPIECE;
+constexpr int H_T_FLOATS = HA + HB + HC + 2 * HC + 8;          // gbias, bias b, bias c, W_d (<= 2 classes), bias d
+constexpr int H_SMEM = H_OFF_T + H_T_FLOATS * 4;
+
+// stream = 20 pieces x 40 fragments.  Slab mb: fragments 0..7 = layer a, tiles 2mb, 2mb+1 (A operand, natural k order:
+// q = (tt * 2 + ks) * 2 + split); 8..39 = layer b, k-step mb of every output tile (q = 8 + 2 t + split, chain k order).
+// Piece 16 + i: fragments 0..31 = layer c, tiles 2i, 2i+1 (q = ((tt * 8 + ks) * 2 + split), chain k order), 32..39 unused.
+__global__ void head_pack_kernel(const float *__restrict__ Wa, const float *__restrict__ Wb, const float *__restrict__ Wc,
+                                 int swa, int swb, int swc, _Float16 *__restrict__ packed) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)H_PIECES * 40 * 512;
+  if (e >= total) return;
+  const int j = e & 7, lane = (e >> 3) & 63, idx = lane & 15, kg = lane >> 4;
+  const int frag = (int)(e >> 9), piece = frag / 40, q = frag % 40;
+  float w = 0.f;
+  int split = 0;
+  if (piece < H_SLABS) {
+    if (q < 8) {
+      split = q & 1;
+      const int ks = (q >> 1) & 1, tt = q >> 2;
+      w = ldexpf(Wa[(size_t)(32 * piece + 16 * tt + idx) * C1 + 32 * ks + 8 * kg + j], swa);
+    } else {
+      split = q & 1;
+      const int t = (q - 8) >> 1;
+      w = ldexpf(Wb[(size_t)(16 * t + idx) * HA + chain_k(piece, kg, j)], swb);
+    }
+  } else if (q < 32) {
+    split = q & 1;
+    const int ks = (q >> 1) & 7, tt = q >> 4, tile = 2 * (piece - H_SLABS) + tt;
+    w = ldexpf(Wc[(size_t)(16 * tile + idx) * HB + chain_k(ks, kg, j)], swc);
+  }
+  const _Float16 hi = (_Float16)w;
+  const _Float16 lo = (_Float16)(w - (float)hi);
+  packed[e] = split == 0 ? hi : lo;
+}
+
+struct HeadArgs {
+  int M, P, ldx, n_cls;
+  const float *x;
+  const half8 *packed;
+  const float *gbias, *bb, *bc, *Wd, *bd;
+  float ascale, osa, osb, osc;
+  float *out;
+  unsigned *status;
+};
+
+__global__ __launch_bounds__(512) void head_kernel(HeadArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[H_SMEM];
+  float *s_ga = reinterpret_cast<float *>(smem + H_OFF_T), *s_bb = s_ga + HA, *s_bc = s_bb + HB, *s_wd = s_bc + HC;
+  float *s_bd = s_wd + 2 * HC;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
+  const int prop = blockIdx.x;
+  const char *gp = reinterpret_cast<const char *>(a.packed);
+  unsigned amax16 = 0u;
+  for (int i = t; i < HA; i += 512) s_ga[i] = a.gbias[(size_t)prop * HA + i];
+  for (int i = t; i < HB; i += 512) s_bb[i] = a.bb[i];
+  for (int i = t; i < HC; i += 512) s_bc[i] = a.bc[i];
+  for (int i = t; i < 2 * HC; i += 512) s_wd[i] = i < a.n_cls * HC ? a.Wd[i] : 0.f;
+  if (t < 2) s_bd[t] = t < a.n_cls ? a.bd[t] : 0.f;
+  const int passes = a.P / 128, total_pieces = passes * H_PIECES;
+  auto dma_piece = [&](int p) {          // wave w moves fragments 5w .. 5w+4 of piece p (40 fragments)
+    const char *src = gp + (size_t)(p % H_PIECES) * HPIECE + (wave * 5) * 1024 + lane * 16;
+    unsigned char *dst = smem + (p % 3) * HPIECE + (wave * 5) * 1024;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + q * 1024), (lds_void *)(dst + q * 1024), 16, 0, 0);
+  };
+  auto end_piece = [&](int p) {          // the piece after p must have landed before anybody reads it
+    __builtin_amdgcn_sched_barrier(0);
+    if (p + 2 < total_pieces) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  dma_piece(0);
+  dma_piece(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int pass = 0; pass < passes; ++pass) {
+    const size_t row = (size_t)prop * a.P + (size_t)pass * 128 + wave * 16 + n;
+    const float *xr = a.x + row * (size_t)a.ldx;
+    half8 inhi[2], inlo[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const f32x4 u0 = *reinterpret_cast<const f32x4 *>(xr + 32 * ks + 8 * g);
+      const f32x4 u1 = *reinterpret_cast<const f32x4 *>(xr + 32 * ks + 8 * g + 4);
+      unsigned hw[4], lw[4];
+      split2(u0[0] * a.ascale, u0[1] * a.ascale, hw[0], lw[0], amax16);
+      split2(u0[2] * a.ascale, u0[3] * a.ascale, hw[1], lw[1], amax16);
+      split2(u1[0] * a.ascale, u1[1] * a.ascale, hw[2], lw[2], amax16);
+      split2(u1[2] * a.ascale, u1[3] * a.ascale, hw[3], lw[3], amax16);
+      inhi[ks] = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+      inlo[ks] = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+    }
+    f32x4 H2[16];
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) H2[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- 16 slabs: layer a tiles (2mb, 2mb+1) -> ReLU -> k-step mb of layer b
+    for (int mb = 0; mb < H_SLABS; ++mb) {
+      const int p = pass * H_PIECES + mb;
+      if (p + 2 < total_pieces) dma_piece(p + 2);
+      const half8 *w = reinterpret_cast<const half8 *>(smem + (p % 3) * HPIECE) + lane;
+      f32x4 da[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const half8 wh = w[((tt * 2 + ks) * 2) * 64], wl = w[((tt * 2 + ks) * 2 + 1) * 64];
+          acc = mfma16(wh, inhi[ks], acc);
+          acc = mfma16(wh, inlo[ks], acc);
+          acc = mfma16(wl, inhi[ks], acc);
+        }
+        da[tt] = acc;
+      }
+      half8 bhi, blo;
+      act_pair(da[0], da[1], s_ga, 32 * mb + g4, a.osa, a.ascale, bhi, blo, amax16);
+      __builtin_amdgcn_sched_barrier(0);
+      half8 cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cw[q] = w[(8 + q) * 64];
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp) {          // two output tiles of layer b per step
+        __builtin_amdgcn_sched_barrier(0);
+        half8 nw[4];
+        if (tp < 7) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nw[q] = w[(8 + 4 * (tp + 1) + q) * 64];
+        }
+        H2[2 * tp] = mfma16(cw[0], bhi, H2[2 * tp]);
+        H2[2 * tp + 1] = mfma16(cw[2], bhi, H2[2 * tp + 1]);
+        H2[2 * tp] = mfma16(cw[0], blo, H2[2 * tp]);
+        H2[2 * tp + 1] = mfma16(cw[2], blo, H2[2 * tp + 1]);
+        H2[2 * tp] = mfma16(cw[1], bhi, H2[2 * tp]);
+        H2[2 * tp + 1] = mfma16(cw[3], bhi, H2[2 * tp + 1]);
+        asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]));
+        if (tp < 7) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cw[q] = nw[q];
+        }
+      }
+      end_piece(p);
+    }
+    // ---- layer b -> ReLU -> layer c (two output tiles per piece), -> ReLU -> scores on the VALU
+    half8 chi[8], clo[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      act_pair(H2[2 * ks], H2[2 * ks + 1], s_bb, 32 * ks + g4, a.osb, a.ascale, chi[ks], clo[ks], amax16);
+    float sc0 = 0.f, sc1 = 0.f;
+    for (int i = 0; i < H_CPIECES; ++i) {
+      const int p = pass * H_PIECES + H_SLABS + i;
+      if (p + 2 < total_pieces) dma_piece(p + 2);
+      const half8 *w = reinterpret_cast<const half8 *>(smem + (p % 3) * HPIECE) + lane;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        half8 ch_ = w[(tt * 16) * 64], cl_ = w[(tt * 16 + 1) * 64];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          __builtin_amdgcn_sched_barrier(0);
+          half8 nh, nl;
+          if (ks < 7) {
+            nh = w[(tt * 16 + 2 * ks + 2) * 64];
+            nl = w[(tt * 16 + 2 * ks + 3) * 64];
+          }
+          acc = mfma16(ch_, chi[ks], acc);
+          acc = mfma16(ch_, clo[ks], acc);
+          acc = mfma16(cl_, chi[ks], acc);
+          asm volatile("" ::"v"(ch_), "v"(cl_));
+          if (ks < 7) {
+            ch_ = nh;
+            cl_ = nl;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // lane (point n, g): channels 16 tile + 4 g + r of the 128-wide layer -> bias, ReLU, partial scores
+        const int ch = 16 * (2 * i + tt) + g4;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(s_bc + ch);
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(s_wd + ch), w1 = *reinterpret_cast<const f32x4 *>(s_wd + HC + ch);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = __builtin_fmaf(acc[r], a.osc, bv[r]);
+          v = v > 0.f ? v : 0.f;
+          sc0 = __builtin_fmaf(w0[r], v, sc0);
+          sc1 = __builtin_fmaf(w1[r], v, sc1);
+        }
+      }
+      end_piece(p);
+    }
+    sc0 += __shfl_xor(sc0, 16);
+    sc0 += __shfl_xor(sc0, 32);
+    sc1 += __shfl_xor(sc1, 16);
+    sc1 += __shfl_xor(sc1, 32);
+    if (lane < 16) {
+      a.out[row * a.n_cls] = sc0 + s_bd[0];
+      if (a.n_cls > 1) a.out[row * a.n_cls + 1] = sc1 + s_bd[1];
+    }
+  }
+  if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(a.status, 4u);
+}
+
 }  // namespace
 
 RFD_API size_t rfd_chain_packed_bytes(void) { return (size_t)W3_BYTES + W2_BYTES + W1_BYTES; }
@@ -359,6 +577,50 @@ RFD_API int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int
   if (mode == 0) hipLaunchKernelGGL(chain_kernel<0>, grid, block, 0, s, a);
   else if (mode == 1) hipLaunchKernelGGL(chain_kernel<1>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(chain_kernel<2>, grid, block, 0, s, a);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API size_t rfd_head_packed_bytes(void) { return (size_t)H_PIECES * HPIECE; }
+
+// Wa [512][64] (conv1's point-feature columns), Wb [256][512], Wc [128][256]: fp32, BatchNorm folded in by the caller.
+RFD_API int rfd_head_pack(const float *Wa, const float *Wb, const float *Wc, int swa, int swb, int swc, void *packed,
+                          void *stream) {
+  if (!Wa || !Wb || !Wc) {
+    rfd_set_error("rfd_head_pack: weights", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  const size_t total = rfd_head_packed_bytes() / 2;
+  hipLaunchKernelGGL(head_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Wa, Wb,
+                     Wc, swa, swb, swc, (_Float16 *)packed);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+// x [M][ldx]: the 64-wide point feature (16-byte aligned rows); gbias [M / P][512] = conv1's bias + its global-feature
+// share per proposal; bb [256], bc [128]; Wd [n_cls][128], bd [n_cls] (n_cls <= 2) -> out [M][n_cls] raw scores.
+RFD_API int rfd_head_scores(int M, int P, const float *x, int ldx, const void *packed, const float *gbias,
+                            const float *bb, const float *bc, const float *Wd, const float *bd, int n_cls, int sa,
+                            int swa, int swb, int swc, float *out, void *stream) {
+  if (M <= 0) return 0;
+  if (P <= 0 || P % 128 || M % P || (ldx & 3) || ((uintptr_t)x & 15) || n_cls < 1 || n_cls > 2 || !gbias || !bb || !bc ||
+      !Wd || !bd || !out) {
+    rfd_set_error("rfd_head_scores: need P % 128 == 0, M % P == 0, 16-byte rows, n_cls <= 2", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  RfdWorkspace *ws;
+  {
+    int rc = rfd_get_workspace(&ws);
+    if (rc) return rc;
+  }
+  HeadArgs a;
+  a.M = M; a.P = P; a.ldx = ldx; a.n_cls = n_cls; a.x = x; a.packed = (const half8 *)packed; a.gbias = gbias;
+  a.bb = bb; a.bc = bc; a.Wd = Wd; a.bd = bd;
+  a.ascale = ldexpf(1.f, sa); a.osa = ldexpf(1.f, -(sa + swa)); a.osb = ldexpf(1.f, -(sa + swb));
+  a.osc = ldexpf(1.f, -(sa + swc));
+  a.out = out;
+  a.status = rfd_status_word(ws, (hipStream_t)stream);
+  hipLaunchKernelGGL(head_kernel, dim3(M / P), dim3(512), 0, (hipStream_t)stream, a);
   RFD_CHECK_LAUNCH();
   return 0;
 }

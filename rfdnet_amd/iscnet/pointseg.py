@@ -184,11 +184,16 @@ class PointSeg(nn.Module):
         if c is None or c[0] is not W:                       # per-point / per-proposal column halves
             c = (W, W[:, 1024:].contiguous(), W[:, :1024].contiguous(), torch.zeros_like(b))
             self.__dict__['_head_split'] = c
-        y = linear_rows(pointfeat, c[1], c[3], relu=True, gbias=F.linear(g, c[2], b).contiguous(),
-                        rows_per_group=P)
-        y = linear_rows(y, *folded(self.conv2, self.bn2), relu=True)
-        y = linear_rows(y, *folded(self.conv3, self.bn3), relu=True)
-        y = F.linear(y, self.conv4.weight[:, :, 0], self.conv4.bias)
+        gbias = F.linear(g, c[2], b).contiguous()                              # (B,512): conv1's global-feature share + bias
+        if chain.head_usable(pointfeat, P, self.k):
+            # conv1 (point-feature columns) -> conv2 -> conv3 -> conv4 in one kernel (csrc/pointseg_chain.hip)
+            y = chain.head_scores(pointfeat, P, c[1], gbias, folded(self.conv2, self.bn2), folded(self.conv3, self.bn3),
+                                  self.conv4.weight[:, :, 0], self.conv4.bias)
+        else:
+            y = linear_rows(pointfeat, c[1], c[3], relu=True, gbias=gbias, rows_per_group=P)
+            y = linear_rows(y, *folded(self.conv2, self.bn2), relu=True)
+            y = linear_rows(y, *folded(self.conv3, self.bn3), relu=True)
+            y = F.linear(y, self.conv4.weight[:, :, 0], self.conv4.bias)
         return F.log_softmax(y, dim=-1).view(B, P, self.k), trans_feat
 
     def _forward_factored(self, x):

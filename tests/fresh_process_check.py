@@ -136,7 +136,18 @@ def check_chain(seed):
             h = torch.relu(h)
         ref = h.view(3, 1024, 1024).max(dim=1)[0]
         worst = max(worst, (a.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
-    assert worst < 2e-5, "fused chain off by %.3g (relative)" % worst
+    # ... and PointSeg's fused head (same ring machinery, 40-KiB pieces)
+    (Wa, _), lb, lc, (Wd, bd) = lin(512, 64), lin(256, 512), lin(128, 256), lin(2, 128)
+    gbias = torch.randn(3, 512, device="cuda", generator=g)
+    x = torch.randn(3 * 1024, 64, device="cuda", generator=g)
+    a = chain.head_scores(x, 1024, Wa, gbias, lb, lc, Wd, bd)
+    b = chain.head_scores(x, 1024, Wa, gbias, lb, lc, Wd, bd)
+    assert torch.equal(a, b), "fused head: two runs on the same input differ"
+    h = torch.relu(x.double() @ Wa.double().t() + gbias.double().repeat_interleave(1024, 0))
+    h = torch.relu(torch.relu(h @ lb[0].double().t() + lb[1].double()) @ lc[0].double().t() + lc[1].double())
+    ref = h @ Wd.double().t() + bd.double()
+    worst = max(worst, (a.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
+    assert worst < 2e-5, "fused chain / head off by %.3g (relative)" % worst
     return worst
 
 

@@ -83,3 +83,27 @@ def test_chain_flags_activations_beyond_the_f16_range(hip):
     chain.chain_pool(x, l1, l2, l3, 1024, True)
     with pytest.raises(hip.RfdHipError, match="split-precision GEMM"):
         hip.device_status()
+
+
+@pytest.mark.parametrize("B,P,n_cls", [(3, 1024, 2), (2, 384, 2), (4, 1024, 1)])
+def test_head_matches_fp64_composition(hip, B, P, n_cls):
+    """64 -> 512 (+ per-proposal bias, ReLU) -> 256 (ReLU) -> 128 (ReLU) -> n_cls scores (pointseg.py:131-154 folded)."""
+    from rfdnet_amd import chain
+    g = torch.Generator(device="cuda").manual_seed(40 + P + n_cls)
+
+    def lin(n, k, scale=2.0):
+        return ((torch.rand(n, k, device="cuda", generator=g) * 2 - 1) * scale / np.sqrt(k),
+                torch.randn(n, device="cuda", generator=g) * 0.3)
+    (Wa, _), lb, lc, (Wd, bd) = lin(512, 64), lin(256, 512), lin(128, 256), lin(n_cls, 128)
+    gbias = torch.randn(B, 512, device="cuda", generator=g)
+    x = torch.randn(B * P, 64, device="cuda", generator=g) * 1.5
+    assert chain.head_usable(x, P, n_cls)
+    out = chain.head_scores(x, P, Wa, gbias, lb, lc, Wd, bd)
+    hip.device_status()
+    h = torch.relu(x.double() @ Wa.double().t() + gbias.double().repeat_interleave(P, 0))
+    h = torch.relu(h @ lb[0].double().t() + lb[1].double())
+    h = torch.relu(h @ lc[0].double().t() + lc[1].double())
+    ref = h @ Wd.double().t() + bd.double()
+    err = (out.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    print("head B %d P %d k %d: max |out - fp64| / max(1, |ref|) = %.2e (|ref| up to %.2f)" % (B, P, n_cls, err, ref.abs().max().item()))
+    assert out.shape == (B * P, n_cls) and err < 2e-5
