@@ -65,3 +65,29 @@ def test_decoder8_prefetch_never_lands_on_recently_read_mfma_sources(tmp_path):
     old = _asm(tmp_path, "occ_decoder8.hip", "dec8_r0.s", ("-DDEC8_ROT=0", "-DDEC8_FENCE=1"))
     st, problems = audit_mfma_war.audit(old, "occ_decode8_kernelILi3E", min_mfma_gap=6, min_c_states=3)
     assert st['min_ab_gap'] == 0 and len(problems) > 50, (st, len(problems))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
+                    reason="hipcc not available")
+def test_no_kernel_runs_its_waves_at_unequal_priorities(tmp_path):
+    """Round 2's wrong results needed two ingredients: loads landing on just-read MFMA sources (what every
+    hipcc-scheduled MFMA kernel has -- the audit counts them below for the record) AND unequal wave priorities.  The
+    eight-wave decoder is built so that the first cannot happen (test above); every OTHER matrix-core kernel keeps
+    hipcc's own placement, so the second must stay out: no `s_setprio` anywhere in the shipped library."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_mfma_war
+    report = []
+    for src, kernels in (("occ_decoder.hip", ["occ_decode_kernelILi3E"]),
+                         ("gemm_f16x3.hip", ["gemm_f16x3_kernel", "gemm_rows8_kernelILb1ELb0E"]),
+                         ("sa_fused.hip", ["sa_fused_kernelILi4E"]),
+                         ("pointseg_chain.hip", ["chain_kernelILi1E", "head_kernel"]),
+                         ("occ_decoder8.hip", ["occ_decode8_kernelILi3E"])):
+        asm = _asm(tmp_path, src, src + ".s")
+        text = open(asm).read()
+        assert "s_setprio" not in text, src
+        for k in kernels:
+            st, problems = audit_mfma_war.audit(asm, k, min_mfma_gap=6, min_c_states=3)
+            assert st['mfma'] > 0, (src, k)
+            report.append("%s %s: %d MFMAs, %d loads, closest load to an MFMA source: %s MFMAs, findings %d"
+                          % (src, k, st['mfma'], st['loads'], st['min_ab_gap'], len(problems)))
+    print("\n".join(report))
