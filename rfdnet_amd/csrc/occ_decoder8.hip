@@ -191,17 +191,23 @@ __device__ __forceinline__ void dma_piece8(const half8 *__restrict__ packed, uns
 
 // ---- weight-fragment prefetch with PROVABLY disjoint destinations --------------------------------------------
 // A k-step's four fragments (hi/lo of two channel tiles) are fetched one step ahead.  Round 2 let the compiler
-// place them: it reused the registers the previous step's MFMAs had just read as SrcA (0-6 wait states earlier) and
-// sank a slab's last MFMAs below the slab-end barrier, right in front of the next slab's loads into their source
-// registers; with unequal wave priorities that build returned wrong 16-point groups (profiles/r03_decoder_hazard.txt:
-// reproduced from the git history in round 3, 10/10 cold processes; ONE sched_barrier in front of the barrier makes
-// it clean).  Now THREE sets rotate -- in use (cur), in flight (nxt), last read (prv) -- and the structure, not the
-// allocator's mood, keeps them apart:
+// place them: it reused the registers the previous step's MFMAs had just read as SrcA (0-6 wait states earlier),
+// renamed accumulators between MFMAs and sank a slab's last MFMAs below the slab-end barrier.  With unequal static
+// wave priorities that build returned wrong 16-point groups (reproduced from the git history in round 3, 10/10 cold
+// processes).  profiles/r03_decoder_hazard.txt sections 7-8: an assembly-level bisect of the failing binary ties the
+// failure to the code layout modulo 32 bytes and to a window of a few wait states in front of ONE block-input MFMA of
+// the low-priority wave; the sunk MFMAs / reused source registers are NOT the cause (moving them back or 512 wait
+// states in between change nothing), five isolated hardware mechanisms are excluded, the hardware cause is open.
+// What is known to hold: no s_setprio -> never wrong (thousands of cold processes); and the structure below, WITH
+// the priority put back, is clean at all eight code layouts where round 2's structure fails at three.  So THREE
+// sets rotate -- in use (cur), in flight (nxt), last read (prv) -- and the structure, not the allocator's mood,
+// keeps them apart:
 //   * step_fence(): nothing is scheduled across a k-step boundary or across a barrier;
 //   * keep_alive(cur, prv) at the END of every step: both sets stay allocated for the whole step, so neither the
 //     prefetch destinations nor any other load issued in step k (conditioning-table reads) can be given a register
 //     that the MFMAs of step k or k-1 read.  A destination was therefore last read >= one whole k-step (six
-//     MFMAs) earlier.  tools/audit_mfma_war.py checks exactly that on the generated assembly (CPU suite).
+//     MFMAs) earlier.  tools/audit_mfma_war.py checks exactly that on the generated assembly (CPU suite) -- a
+//     conservative invariant of the generated code, not the proof of a root cause.
 // The loads themselves are plain loads: hipcc counts them (lgkmcnt) and pads the MFMA-SrcC write-after-read states
 // itself.  (An asm-issued variant measured 1 % faster in one build and returned WRONG logits in another: hipcc may
 // copy an asm load's destination register before the data has landed -- it does not know the load is in flight.)
@@ -263,10 +269,10 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g4 = 4 * (lane >> 4), n = lane & 15;
   unsigned amax16 = 0u;
-  // No static priority in the shipped build (+0.6 % at best).  Round 2: a static priority for the later-dispatched
-  // half of the workgroup, together with the compiler-placed fragment prefetch (DEC8_ROT 0), produced wrong
-  // 16-point groups in 80-100 % of fresh processes -- profiles/r02_decoder_ablation.txt section 5,
-  // profiles/r03_decoder_hazard.txt for what round 3 found and why the prefetch is now built as it is.
+  // NO static priority in the shipped build, and tests/test_isa_audit.py refuses one: unequal priorities of a SIMD's
+  // two waves are the one necessary condition of round 2's wrong 16-point groups that is understood (the rest is code
+  // layout and a timing window at one MFMA issue: profiles/r03_decoder_hazard.txt sections 7-8), and they buy nothing
+  // (+-0.3 %).  DEC8_PRIO exists for the side builds that put the priority back on purpose (tools/ab/).
 #if DEC8_PRIO
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif

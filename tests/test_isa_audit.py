@@ -49,8 +49,11 @@ def _asm(tmp_path, src, name, extra=()):
 def test_decoder8_prefetch_never_lands_on_recently_read_mfma_sources(tmp_path):
     """The eight-wave decoder's weight-fragment prefetch (and every other LDS / global load in the kernel) must
     not write a register that one of the last SIX MFMAs read as SrcA / SrcB (unless that MFMA is 32 or more wait
-    states back), nor one read as SrcC fewer than three wait states earlier (tools/audit_mfma_war.py on the shipped build's assembly; the round-2 build, whose prefetch
-    reused the registers of the MFMAs issued just before, is the control: the audit must flag it).  No spills."""
+    states back), nor one read as SrcC fewer than three wait states earlier (tools/audit_mfma_war.py on the shipped
+    build's assembly; the round-2 build, whose prefetch reused the registers of the MFMAs issued just before, is the
+    control: the audit must flag it).  No spills.  This is a conservative invariant of the generated code -- the
+    structure that stays clean with a static priority at every code layout has it, round 2's does not -- and NOT the
+    root cause of round 2's failure (profiles/r03_decoder_hazard.txt section 7)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_mfma_war
     asm = _asm(tmp_path, "occ_decoder8.hip", "dec8.s")
@@ -70,10 +73,11 @@ def test_decoder8_prefetch_never_lands_on_recently_read_mfma_sources(tmp_path):
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
                     reason="hipcc not available")
 def test_no_kernel_runs_its_waves_at_unequal_priorities(tmp_path):
-    """Round 2's wrong results needed two ingredients: loads landing on just-read MFMA sources (what every
-    hipcc-scheduled MFMA kernel has -- the audit counts them below for the record) AND unequal wave priorities.  The
-    eight-wave decoder is built so that the first cannot happen (test above); every OTHER matrix-core kernel keeps
-    hipcc's own placement, so the second must stay out: no `s_setprio` anywhere in the shipped library."""
+    """The one NECESSARY condition of round 2's wrong results that is understood is unequal static priorities of the
+    two waves of a SIMD (the rest: code layout modulo 32 bytes and a timing window at one MFMA issue, hardware cause
+    open -- profiles/r03_decoder_hazard.txt sections 7-8; without `s_setprio` the failing binary itself is clean).
+    Every matrix-core kernel keeps hipcc's own instruction placement somewhere, so the priority must stay out: no
+    `s_setprio` anywhere in the shipped library.  (The audit's counts are printed for the record.)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_mfma_war
     report = []

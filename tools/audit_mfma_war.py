@@ -3,7 +3,9 @@
 For every instruction that writes VGPRs ASYNCHRONOUSLY (ds_read*, global/buffer/scratch loads that are not LDS-DMA:
 their data lands whenever the memory pipe returns it, not in program order with the matrix pipe) find the most recent
 v_mfma that READ one of those registers as SrcA / SrcB / SrcC and report the distance in issued MFMAs and in wait
-states.  Rules (profiles/r03_decoder_hazard.txt):
+states.  A conservative invariant of the shipped decoder's generated code (profiles/r03_decoder_hazard.txt): it was
+designed against the round's first attribution of round 2's failure, which section 7 there refutes -- the failing build
+violates it 213 times, but repairing the violations does not repair that build.  Rules:
   A/B: a load destination must not alias SrcA or SrcB of any of the last `min_mfma_gap` MFMAs, unless that MFMA is
        at least 32 wait states back (round 2's failing decoder reused the registers of the MFMAs issued 0-6 wait
        states earlier);
