@@ -10,7 +10,11 @@ static priority of commit 0872592 put back:
   fdprio_nN   fdprio + N wait states (s_nop) between the sunk MFMAs and the next slab's table loads, N = 1 .. 32:
               the distance at which the real kernel stops failing
   fdprio_vN   fdprio + N v_nop (VALU no-ops, which go through the vector issue port like the MFMAs do) at the same place
--> rfdnet_amd/lib/variants/librfd_<name>.so (git-ignored, travels with gpurun); tools/ab/prio_check.py runs them."""
+-> rfdnet_amd/lib/variants/librfd_<name>.so (git-ignored, travels with gpurun); tools/ab/prio_check.py runs them.
+NOTE: these are SOURCE-level variants -- one added statement lets hipcc re-allocate and re-schedule the whole kernel (fdprio
+vs fdprio_sb: 1258 differing assembly lines), so a clean variant says nothing about the site of the statement.
+tools/ab/asm_variants.py edits the failing build's assembly instead (profiles/r03_decoder_hazard.txt section 7)."""
+usage = "python tools/ab/make_hist_variants.py [name ...]   (no names: all)"
 import os
 import subprocess
 import sys
