@@ -82,6 +82,7 @@ static void run(int iters, unsigned *bad) {
   printf("wait_states=%2d own_mfma_in_front=%d aggressor=%s : stale SrcC %u other %u %s\n", NV, PRE,
          !AGG ? "none      " : PRIO == 0 ? "equal prio" : PRIO == 1 ? "prio 1    " : "prio 3    ", h[0], h[1],
          (h[0] | h[1]) ? "BAD" : "ok");
+  fflush(stdout);
 }
 
 template <int PRE, int PRIO, int AGG>
@@ -90,29 +91,23 @@ static void sweep(int iters, unsigned *bad) {
   run<4, PRE, PRIO, AGG>(iters, bad);
   run<6, PRE, PRIO, AGG>(iters, bad);
   run<8, PRE, PRIO, AGG>(iters, bad);
-  run<9, PRE, PRIO, AGG>(iters, bad);
   run<10, PRE, PRIO, AGG>(iters, bad);
-  run<11, PRE, PRIO, AGG>(iters, bad);
   run<12, PRE, PRIO, AGG>(iters, bad);
-  run<13, PRE, PRIO, AGG>(iters, bad);
-  run<14, PRE, PRIO, AGG>(iters, bad);
   run<15, PRE, PRIO, AGG>(iters, bad);
-  run<16, PRE, PRIO, AGG>(iters, bad);
   run<20, PRE, PRIO, AGG>(iters, bad);
-  run<24, PRE, PRIO, AGG>(iters, bad);
 }
 
 int main(int argc, char **argv) {
-  const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+  const int iters = argc > 1 ? atoi(argv[1]) : 300;
   unsigned *bad;
   (void)hipMalloc(&bad, 64 * sizeof(unsigned));
-  sweep<0, 0, 0>(iters, bad);
-  sweep<1, 0, 0>(iters, bad);
-  sweep<0, 0, 1>(iters, bad);
-  sweep<1, 0, 1>(iters, bad);
-  sweep<0, 1, 1>(iters, bad);
+  // the priority legs first (a starved victim is slow: keep iters small)
   sweep<1, 1, 1>(iters, bad);
   sweep<1, 3, 1>(iters, bad);
+  sweep<0, 1, 1>(iters, bad);
+  sweep<0, 3, 1>(iters, bad);
+  sweep<1, 0, 1>(iters, bad);
+  sweep<1, 0, 0>(iters, bad);
   printf("TOTAL bad at >= 12 wait states: %u (%d iterations x 512 workgroups x 4 victim waves per configuration)\n", g_total, iters);
   return 0;
 }
