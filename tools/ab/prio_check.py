@@ -14,7 +14,13 @@ for name in sys.argv[2:]:
         env["RFD_HIP_LIB"] = os.path.join(ROOT, "rfdnet_amd", "lib", "variants", "librfd_%s.so" % name)
     bad, detail, err = 0, [], 0
     for i in range(n):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg_map.py")], env=env, capture_output=True, text=True)
+        try:      # a hand-edited build may hang: never let one process eat the GPU box's time limit
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg_map.py")], env=env, capture_output=True,
+                               text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            err += 1
+            detail.append("timed out after 240 s")
+            break
         lines = [l for l in r.stdout.splitlines() if "BAD" in l]
         if r.returncode != 0:
             err += 1
