@@ -194,10 +194,14 @@ __device__ __forceinline__ void dma_piece8(const half8 *__restrict__ packed, uns
 // place them: it reused the registers the previous step's MFMAs had just read as SrcA (0-6 wait states earlier),
 // renamed accumulators between MFMAs and sank a slab's last MFMAs below the slab-end barrier.  With unequal static
 // wave priorities that build returned wrong 16-point groups (reproduced from the git history in round 3, 10/10 cold
-// processes).  profiles/r03_decoder_hazard.txt sections 7-8: an assembly-level bisect of the failing binary ties the
-// failure to the code layout modulo 32 bytes and to a window of a few wait states in front of ONE block-input MFMA of
-// the low-priority wave; the sunk MFMAs / reused source registers are NOT the cause (moving them back or 512 wait
-// states in between change nothing), five isolated hardware mechanisms are excluded, the hardware cause is open.
+// processes).  profiles/r03_decoder_hazard.txt sections 7-9: the sunk MFMAs / reused source registers are NOT the cause
+// (an assembly-level bisect of the failing binary: moving them back or 512 wait states in between change nothing).
+// What goes wrong is one VALU move at the END of the tile prologue (fc_p) of the LOW-priority wave: it reads 0 where an
+// LDS-loaded weight should be, in lanes 48-63, so ONE channel of H' loses its y term -- every one of 60 dumped wrong
+// groups is explained exactly by that (tools/fault_model.py) -- while the wave's SIMD partner, at the higher priority,
+// is ~250 instructions ahead in the block-input code's LDS bursts and MFMAs (no barrier in between); whether it
+// happens depends on the code layout modulo 32 bytes and on the partner's timing.  Six isolated hardware mechanisms
+// are excluded by micro reproducers; the hardware cause is open.
 // What is known to hold: no s_setprio -> never wrong (thousands of cold processes); and the structure below, WITH
 // the priority put back, is clean at all eight code layouts where round 2's structure fails at three.  So THREE
 // sets rotate -- in use (cur), in flight (nxt), last read (prv) -- and the structure, not the allocator's mood,
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   unsigned amax16 = 0u;
   // NO static priority in the shipped build, and tests/test_isa_audit.py refuses one: unequal priorities of a SIMD's
   // two waves are the one necessary condition of round 2's wrong 16-point groups that is understood (the rest is code
-  // layout and a timing window at one MFMA issue: profiles/r03_decoder_hazard.txt sections 7-8), and they buy nothing
+  // layout and the timing of the partner wave's path: profiles/r03_decoder_hazard.txt sections 7-9), and they buy nothing
   // (+-0.3 %).  DEC8_PRIO exists for the side builds that put the priority back on purpose (tools/ab/).
 #if DEC8_PRIO
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);

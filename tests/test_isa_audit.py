@@ -53,7 +53,7 @@ def test_decoder8_prefetch_never_lands_on_recently_read_mfma_sources(tmp_path):
     build's assembly; the round-2 build, whose prefetch reused the registers of the MFMAs issued just before, is the
     control: the audit must flag it).  No spills.  This is a conservative invariant of the generated code -- the
     structure that stays clean with a static priority at every code layout has it, round 2's does not -- and NOT the
-    root cause of round 2's failure (profiles/r03_decoder_hazard.txt section 7)."""
+    root cause of round 2's failure (profiles/r03_decoder_hazard.txt sections 7-9)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_mfma_war
     asm = _asm(tmp_path, "occ_decoder8.hip", "dec8.s")
@@ -74,8 +74,9 @@ def test_decoder8_prefetch_never_lands_on_recently_read_mfma_sources(tmp_path):
                     reason="hipcc not available")
 def test_no_kernel_runs_its_waves_at_unequal_priorities(tmp_path):
     """The one NECESSARY condition of round 2's wrong results that is understood is unequal static priorities of the
-    two waves of a SIMD (the rest: code layout modulo 32 bytes and a timing window at one MFMA issue, hardware cause
-    open -- profiles/r03_decoder_hazard.txt sections 7-8; without `s_setprio` the failing binary itself is clean).
+    two waves of a SIMD (the rest: a VALU move of the low-priority wave's tile prologue reading 0 for an LDS-loaded
+    weight while its partner is far ahead, as a function of code layout and timing; hardware cause open --
+    profiles/r03_decoder_hazard.txt sections 7-9; without `s_setprio` the failing binary itself is clean).
     Every matrix-core kernel keeps hipcc's own instruction placement somewhere, so the priority must stay out: no
     `s_setprio` anywhere in the shipped library.  (The audit's counts are printed for the record.)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -11,6 +11,9 @@ c = torch.from_numpy(rng.normal(0, 1, (K, 512)).astype(np.float32)).cuda()
 with torch.no_grad():
     outs = [dec(p, z, c).cpu().numpy() for _ in range(8)]
 ref = np.median(np.stack(outs), axis=0)          # majority value per point
+if os.environ.get("RFD_DBG_DUMP"):               # the eight launches' logits, for tools/fault_model.py
+    os.makedirs(os.environ["RFD_DBG_DUMP"], exist_ok=True)
+    np.save(os.path.join(os.environ["RFD_DBG_DUMP"], "outs_%d.npy" % os.getpid()), np.stack(outs))
 for r, o in enumerate(outs):
     bad = np.abs(o - ref) > 1e-5
     if bad.any():
