@@ -5,6 +5,9 @@ binary in exactly the lines named:
   a0     no edit (round trip through the assembler: must fail like fdprio)
   up     the five MFMAs hipcc sank below the slab-end s_barrier moved back in front of it
   upK    only the first K of them moved
+  w0     the three partial s_waitcnt lgkmcnt(n) in front of the faulty prologue moves (section 8) made full waits
+  pb     s_barrier + 7 s_nop between the tile prologue and the block-input code (control: ins581x8, the same 32 bytes
+         without the barrier)
   bn32   32 wait states between that s_barrier and the five MFMAs
   tn64   64 wait states behind the five MFMAs on BOTH paths (in front of the s_cbranch), none at the loads
 -> rfdnet_amd/lib/variants/librfd_fdasm_<name>.so; tools/ab/prio_check.py runs them.
@@ -55,6 +58,10 @@ def real_instructions(lines):
         if t and not t.startswith(".") and not t.endswith(":"):
             out.append(i)
     return out
+
+
+def out_is_branch(line):
+    return line.split(";")[0].strip().startswith("s_branch")
 
 
 def everywhere(lines, match, before=(), after=(), pick=None):
@@ -122,6 +129,18 @@ def edit(lines, name):
         out.insert(r[b] + 1, moved)
         del out[r[a] if a < b else r[a] + 1]
         return out
+    if name == "w0":                      # the three partial LDS waits in front of the faulty moves -> full waits (same size)
+        r = real_instructions(lines)
+        out = list(lines)
+        for k in (541, 560, 563):
+            assert out[r[k]].split(";")[0].strip().startswith("s_waitcnt lgkmcnt("), out[r[k]]
+            out[r[k]] = "\ts_waitcnt lgkmcnt(0)"
+        return out
+    if name == "pb":                      # s_barrier + 7 s_nop (32 bytes) between the tile prologue and the block-input code
+        r = real_instructions(lines)
+        k = 581
+        assert out_is_branch(lines[r[k]]), lines[r[k]]
+        return lines[:r[k]] + ["\ts_barrier"] + ["\ts_nop 0"] * 7 + lines[r[k]:]
     if name.startswith("pn_top"):         # N wait states in front of the FIRST LDS-DMA only (same delay, other place)
         n = int(name[6:])
         st, en = kernel_range(lines)
