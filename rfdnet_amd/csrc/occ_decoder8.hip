@@ -328,6 +328,13 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
         v = __builtin_fmaf(s_wp[ch * 3 + 2], pz, v);
         Hs[tt][r] = v;
       }
+    // All eight waves finish the prologue's LDS reads before any of them enters the block-input code.  Round 2's wrong
+    // 16-point groups were exactly this stage going wrong in the LOW-priority wave of a SIMD (one fc_p weight read as
+    // 0 in lanes 48-63) while its partner, at a static higher priority, was ~250 instructions ahead in the block-input
+    // code's LDS bursts and MFMAs; on the failing binary a barrier here cures it (0/4 against 4/4 for the same bytes
+    // without it: profiles/r03_decoder_hazard.txt section 8).  The shipped build has no priorities and never showed
+    // the fault, so this is a belt: one barrier per tile, next to ~45 others.
+    __syncthreads();
 
     half8 ahi[8], alo[8];
     for (int blk = 0; blk < NB; ++blk) {
