@@ -176,7 +176,7 @@ def main(names, shipped=False, cur_tag="shasm", cur_flags=("-DDEC8_PRIO=1",)):
     os.makedirs(tmp, exist_ok=True)
     flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared",)]
     if shipped:
-        src = os.path.join(ROOT, "rfdnet_amd", "csrc", "occ_decoder8.hip")
+        src = os.environ.get("RFD_ASM_SRC") or os.path.join(ROOT, "rfdnet_amd", "csrc", "occ_decoder8.hip")
         flags = flags + list(cur_flags)
         base_s = os.path.join(tmp, cur_tag + ".dev.s")
     else:
