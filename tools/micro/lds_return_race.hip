@@ -17,7 +17,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int PRIO, int NOPS, int AGG>
+template <int PRIO, int NOPS, int AGG, int BC>
 __global__ __launch_bounds__(512) void k(int iters, unsigned *bad) {
   __shared__ __attribute__((aligned(16))) unsigned s_pat[8][3][64][4];      // round, load, lane, dword
   __shared__ __attribute__((aligned(16))) half8 s_frag[64][64];             // aggressor's fragments (64 KiB)
@@ -60,8 +60,11 @@ __global__ __launch_bounds__(512) void k(int iters, unsigned *bad) {
     unsigned nbad[4] = {0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
       const int rd = it & 7;
-      const unsigned a0 = (unsigned)(size_t)&s_pat[rd][0][lane][0], a1 = (unsigned)(size_t)&s_pat[rd][1][lane][0],
-                     a2 = (unsigned)(size_t)&s_pat[rd][2][lane][0];
+      // BC 1: the prologue's addressing -- the 16 lanes of a quarter read the SAME 16 bytes, the quarters 48 bytes apart,
+      // the second load the adjacent 16 bytes (fc_p's weights of four channels per quarter)
+      const int el = BC ? 3 * (lane >> 4) : lane;
+      const unsigned a0 = (unsigned)(size_t)&s_pat[rd][0][el][0], a1 = (unsigned)(size_t)&s_pat[rd][0][el + 1][0],
+                     a2 = (unsigned)(size_t)&s_pat[rd][BC ? 0 : 2][BC ? el + 2 : lane][0];
       unsigned x0, x1, y, z;
       const unsigned poison = 0x7fc00000u + (unsigned)it;
       asm volatile(
@@ -84,10 +87,10 @@ __global__ __launch_bounds__(512) void k(int iters, unsigned *bad) {
           : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [po] "v"(poison), [nops] "n"(NOPS)
           : "memory", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33",
             "v34", "v35");
-      if (x0 != s_pat[rd][0][lane][1]) nbad[0]++;
-      if (x1 != s_pat[rd][1][lane][0]) nbad[1]++;
-      if (y != s_pat[rd][1][lane][3]) nbad[2]++;
-      if (z != s_pat[rd][2][lane][3]) nbad[3]++;
+      if (x0 != s_pat[rd][0][el][1]) nbad[0]++;
+      if (x1 != s_pat[rd][0][el + 1][0]) nbad[1]++;
+      if (y != s_pat[rd][0][el + 1][3]) nbad[2]++;
+      if (z != s_pat[rd][BC ? 0 : 2][BC ? el + 2 : lane][3]) nbad[3]++;
     }
     for (int i = 0; i < 4; ++i)
       if (nbad[i]) atomicAdd(&bad[4 * (lane >> 4) + i], nbad[i]);       // per quarter of the wave
@@ -97,18 +100,18 @@ __global__ __launch_bounds__(512) void k(int iters, unsigned *bad) {
 
 static unsigned g_total = 0;
 
-template <int PRIO, int NOPS, int AGG>
+template <int PRIO, int NOPS, int AGG, int BC>
 static void run(int iters, unsigned *bad) {
   (void)hipMemset(bad, 0, 64 * sizeof(unsigned));
-  hipLaunchKernelGGL((k<PRIO, NOPS, AGG>), dim3(256), dim3(512), 0, 0, iters, bad);
+  hipLaunchKernelGGL((k<PRIO, NOPS, AGG, BC>), dim3(256), dim3(512), 0, 0, iters, bad);
   unsigned h[64];
   (void)hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost);
   if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(2); }
   unsigned tot = 0;
   for (int i = 0; i < 16; ++i) tot += h[i];
   g_total += tot;
-  printf("aggressor=%s wait_states_behind_waitcnt=%d : stale reads per lane quarter (pk_mov lo, pk_mov hi, mov, mov after full wait)",
-         !AGG ? "none  " : PRIO == 0 ? "equal " : PRIO == 1 ? "prio 1" : "prio 3", NOPS);
+  printf("%s aggressor=%s wait_states_behind_waitcnt=%d : stale reads per lane quarter (pk_mov lo, pk_mov hi, mov, mov after full wait)",
+         BC ? "quarter-broadcast addresses" : "lane-linear addresses      ", !AGG ? "none  " : PRIO == 0 ? "equal " : PRIO == 1 ? "prio 1" : "prio 3", NOPS);
   for (int q = 0; q < 4; ++q) printf("  q%d: %u %u %u %u", q, h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
   printf("  %s\n", tot ? "BAD" : "ok");
   fflush(stdout);
@@ -118,14 +121,14 @@ int main(int argc, char **argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20000;
   unsigned *bad;
   (void)hipMalloc(&bad, 64 * sizeof(unsigned));
-  run<1, 0, 1>(iters, bad);
-  run<3, 0, 1>(iters, bad);
-  run<0, 0, 1>(iters, bad);
-  run<0, 0, 0>(iters, bad);
-  run<1, 1, 1>(iters, bad);
-  run<1, 4, 1>(iters, bad);
-  run<3, 1, 1>(iters, bad);
-  run<1, 0, 1>(iters, bad);
+  run<1, 0, 1, 1>(iters, bad);
+  run<3, 0, 1, 1>(iters, bad);
+  run<0, 0, 1, 1>(iters, bad);
+  run<1, 1, 1, 1>(iters, bad);
+  run<1, 0, 1, 0>(iters, bad);
+  run<3, 0, 1, 0>(iters, bad);
+  run<0, 0, 1, 0>(iters, bad);
+  run<0, 0, 0, 0>(iters, bad);
   printf("TOTAL stale %u (%d rounds x 256 workgroups x 4 victim waves per configuration)\n", g_total, iters);
   return 0;
 }
