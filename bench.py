@@ -76,6 +76,9 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=1,
                     help="scenes per forward pass (batched through every kernel: the latency-bound FPS rounds "
                          "and the ~300 small launches are shared by the batch)")
+    ap.add_argument("--blit-round", type=int, default=0,
+                    help="MISE round whose decode launch the previous scene's device-to-host mesh copy is released "
+                         "behind (0 = the first, longest launch; -1 = at once, when the meshes are complete)")
     ap.add_argument("--mode", choices=["f16x3", "f16x1"], default="f16x3",
                     help="decoder arithmetic; f16x3 is the parity mode (1e-4 on logits)")
     args = ap.parse_args(argv)
@@ -108,6 +111,7 @@ class DecodeTimer(object):
         self.dec = dec
         self.records = []
         self.enabled = False
+        self.round = 0             # MISE round of the next launch (set by the generator's round hook)
         self._orig = dec.decode_tiles
 
         def wrapped(pts, tile_prop, *a, **k):
@@ -121,13 +125,23 @@ class DecodeTimer(object):
                 e1.record()
                 DecodeTimer.last_end = e1
             if self.enabled:
-                self.records.append((int(tile_prop.shape[0]) * 128, e0, e1))
+                self.records.append((int(tile_prop.shape[0]) * 128, e0, e1, self.round))
             return out
         dec.decode_tiles = wrapped
 
     def totals(self):
-        return (sum(e0.elapsed_time(e1) for _, e0, e1 in self.records), sum(n for n, _, _ in self.records),
+        return (sum(e0.elapsed_time(e1) for _, e0, e1, _ in self.records), sum(n for n, _, _, _ in self.records),
                 len(self.records))
+
+    def by_round(self):
+        """{round: [ms, padded points, launches]} of the recorded launches"""
+        out = {}
+        for n, e0, e1, r in self.records:
+            a = out.setdefault(r, [0.0, 0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += n
+            a[2] += 1
+        return out
 
 
 class MeshSink(object):
@@ -203,6 +217,7 @@ class HipBackend(object):
         self.S = max(1, args.in_flight)
         self.NB = max(1, args.batch)
         self.record_scenes, self.scene_records = False, []
+        self.round_points = {}
         self.nets = [self._build_net() for _ in range(self.S)]
         self.timers = [DecodeTimer(n.completion.decoder) for n in self.nets]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.S)]
@@ -260,17 +275,28 @@ class HipBackend(object):
                 ev[1].record()
             sel = net.select_proposals(end_points, 'all', pc)
             gen = net.completion.generator
-            # the previous scene's PCIe copy rides behind the first (longest) decode launch
-            gen.round_hook = lambda r, depth: sink.start_pending() if r == 0 else None
+            # the previous scene's PCIe copy rides behind one decode launch (--blit-round; default the first, longest)
+            tm, blit_round = self.timers[w], self.args.blit_round
+
+            def hook(r, depth):
+                tm.round = r
+                if r == blit_round:
+                    sink.start_pending()
+            gen.round_hook = hook
             # skip propagation -> codes -> completion + the stream's status word (FPS time-out -> raises; an
             # f16-range flag -> one re-run of the stage at the fallback activation scale, raises only if that
             # overflows too)
             meshes = net.reconstruct(end_points, proposal_features, sel, pc,
                                      hook=(lambda codes, cls: ev[2].record()) if ev else None)
-            if self.args.upsampling_steps == 0:
-                sink.start_pending()
+            sink.start_pending()          # (dense grid: no rounds; or fewer rounds than --blit-round)
         v, f, _, _ = gen.last_buffers                              # all K meshes: one vertex / one face buffer
         sink.push(v, f)
+        if self.args.blit_round < 0:
+            sink.start_pending()
+        if self.timers[w].enabled:
+            with DECODE_LOCK:
+                for r, n in enumerate(gen.stats.get('per_round', [])):
+                    self.round_points[r] = self.round_points.get(r, 0) + int(n)
         if ev:
             ev[3].record()
             self.scene_records.append({"scenes": [int(i) for i in ids], "worker": w, "events": ev,
@@ -299,11 +325,31 @@ class HipBackend(object):
             tot = [x + y for x, y in zip(tot, a)]
         return tot
 
+    def per_round(self):
+        """the decoder's launches of the timed region by MISE round (generator.py:99-117): launches, real query points,
+        HIP-event ms, algorithmic TFLOP/s -- locates where the kernel is slower inside a scene than alone"""
+        agg = {}
+        for tm in self.timers:
+            for r, a in tm.by_round().items():
+                b = agg.setdefault(r, [0.0, 0, 0])
+                for i in range(3):
+                    b[i] += a[i]
+        rows = []
+        for r in sorted(agg):
+            ms, padded, launches = agg[r]
+            real = self.round_points.get(r, padded)
+            tf = real * FLOP_PER_QUERY / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            rows.append({"round": r, "launches": launches, "real_points": int(real), "padded_points": int(padded),
+                         "ms": ms, "avg_launch_ms": ms / max(launches, 1), "achieved": tf, "frac": tf / MFMA_PEAK_TFLOPS})
+        return rows
+
     def set_timing(self, on):
         for tm in self.timers:
             tm.enabled = on
             if on:
                 tm.records = []
+        if on:
+            self.round_points = {}
         self.record_scenes = bool(on and getattr(self.args, "stats_out", None))
         if on:
             self.scene_records = []
@@ -420,6 +466,7 @@ class StressBackend(HipBackend):
         self.dist_backend = "gloo" if self.one_dev else "nccl"
         self.args, self.torch, self._lib = args, torch, _lib
         self.S, self.NB, self.world, self.pool = 1, 1, world, world
+        self.round_points = {}
         dec = occ_decoder.DecoderCBatchNorm(dim=3, z_dim=32, c_dim=512, hidden_size=256)
         synthetic.load_seeded(dec, 3)
         dec = dec.to(self.device).eval()
@@ -712,6 +759,7 @@ def main(argv=None):
                                             "process (PMC counters need rocprofv3): %s" % (bpq, bpq_src))
                          if bpq else None,
                          "launches": int(dec_launches),
+                         "per_round": be.per_round() if hasattr(be, "per_round") else None,
                          "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
                          "algorithmic_flop_per_launch": dec_pts * FLOP_PER_QUERY / dec_launches if dec_launches else None,
                          "note": "algorithmic FLOPs (1 312 768 per query point) over HIP-event time of the decoder "

@@ -190,6 +190,13 @@ int rfd_occ_decode_scatter_w8(int n_tiles, const float *pts, const int *tile_pro
                               const float *fc_out_w, float fc_out_b, const int *lin, float *values,
                               unsigned char *pstate, long long n_per, int mode, void *stream);
 
+/* The eight-wave decoder hands its tiles out at run time (a persistent workgroup whose CU is still busy with another
+ * stream's waves at launch starts late; with a static partition it would set the kernel's end): chunk k of a launch
+ * of n_tiles tiles on n_workgroups workgroups covers tiles [*begin, *end) -- batches of n_workgroups equal chunks,
+ * each batch half of what is left, single tiles at the end; *begin == *end == n_tiles past the last chunk.  Host-side
+ * view of the schedule for tests and tools; the kernel evaluates the same function. */
+int rfd_occ_chunk_range(int k, int n_tiles, int n_workgroups, int *begin, int *end);
+
 /* ---- fp32-class GEMM on the f16 matrix cores (csrc/gemm_f16x3.hip) -----------------
  * C[M,N] = act(A)[M,K] . W[N,K]^T (+ bias[N]) (+ gbias[m / rows_per_group][N]) (+ R[M,N]),
  * optional ReLU on A and on C; three f16 MFMAs per product on (hi, lo) operand splits.

@@ -36,6 +36,9 @@ struct RfdWorkspace {
                                   // a flag-raising kernel (rfd_status_word), slot 0 = overflow / default
   std::atomic<void *> status_owner[64];   // stream handle owning each slot (nullptr = free); slot 0 is shared
   float *zeros;                   // RFD_ZEROS_FLOATS zeros (stand-in for absent bias vectors)
+  unsigned *claim;                // RFD_CLAIM_SLOTS pairs {next chunk, workgroups done} of the persistent kernels that
+                                  // hand their tiles out dynamically (occ_decoder8.hip); zero between launches
+  std::atomic<unsigned> claim_seq;
   std::atomic<unsigned> ring_pos;   // callers may come from several host threads / streams
   int num_cu;                     // multiprocessor count of the device
 };
@@ -44,10 +47,16 @@ constexpr int FPS_RING = 16;
 constexpr int FPS_MAX_WG = 256;                         // co-resident WGs/launch
 constexpr int FPS_REGION_GRANULES = FPS_MAX_WG * 2 * 5; // [wg][parity][field]
 constexpr int RFD_STATUS_SLOTS = 64;
+constexpr int RFD_CLAIM_SLOTS = 1024;
 int rfd_get_workspace(RfdWorkspace **ws);
 // The status word kernels launched on `stream` raise their flags in.  Scenes in flight on different streams
 // must not see (or clear) each other's flags: rfd_stream_status(stream) reads and resets this word only.
 unsigned *rfd_status_word(RfdWorkspace *ws, hipStream_t stream);
+// A zeroed counter pair for one launch of a chunk-claiming kernel (the kernel leaves it zeroed again).  Slots are
+// dealt round robin, so launches in flight together never share one unless RFD_CLAIM_SLOTS of them overlap.
+static inline unsigned *rfd_claim_pair(RfdWorkspace *ws) {
+  return ws->claim + 2 * (ws->claim_seq.fetch_add(1, std::memory_order_relaxed) % RFD_CLAIM_SLOTS);
+}
 
 // ---- arithmetic contract ------------------------------------------------------
 // a*a + b*b + c*c as nvcc -fmad=true contracts it (see oracle/rfd_oracle.c

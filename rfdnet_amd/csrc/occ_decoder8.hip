@@ -78,6 +78,43 @@ constexpr int HALF_BYTES = HALF_FRAGS * FRAG_HALVES * 2;                  // 32 
 constexpr int N_HALVES = NB * 8 * 2;
 constexpr int SMEM_BYTES = SMEM_TAB_BYTES + 4 * HALF_BYTES;
 
+// ---- chunk claiming (round 4) ----------------------------------------------------------------------------------
+// The grid is persistent (one workgroup per CU: a workgroup holds a CU's whole register file and 155 KiB of its LDS),
+// so a workgroup whose CU still runs somebody else's waves at launch -- another scene's furthest-point sampling (32
+// workgroups for ~5 ms), a fill, the device-to-host blit of the previous scene's meshes -- cannot start until they
+// have left.  With the static partition of rounds 1-3 (tiles_per_wg consecutive tiles per workgroup) such a late
+// workgroup set the kernel's end: the decoder ran 8 % (64^3) to 15 % (128^3) slower inside a scene than alone.
+// Now the tiles are handed out: chunk k of a "factoring" schedule -- batches of W = gridDim.x chunks, the chunks of
+// batch j all of size s_j = max(1, ceil(R_j / (2 W))), R_j = tiles not yet handed out before batch j -- is taken
+// with one atomicAdd by thread 0 and broadcast through LDS.  The first chunks are large (the first batch is half of the
+// launch: few conditioning-table loads), the last are single tiles (the kernel's tail is at most one tile, ~0.1 ms),
+// and a workgroup that starts late simply takes fewer.  The range of chunk k is a pure function of (k, n_tiles, W):
+// no chunk list, same C ABI.  A chunk may straddle two proposals (the tile loop reloads the table exactly as before);
+// results do not depend on who computes a tile, so they are bit-identical to the static partition's.
+// Counter pair {next chunk, workgroups done} comes from a pool in the workspace (slot = launch sequence number mod
+// RFD_CLAIM_SLOTS, so concurrent launches on different streams never share one) and is reset by the last workgroup
+// to leave: no memset launch in front of the kernel.
+__host__ __device__ __forceinline__ void chunk_range(int k, int n_tiles, int W, int &b, int &e) {
+  int base = 0, rem = n_tiles;
+  const int batch = k / W, i = k - batch * W;
+  for (int q = 0; q < batch && rem > 0; ++q) {
+    int s = (rem + 2 * W - 1) / (2 * W);
+    s = s < 1 ? 1 : s;
+    const int take = s * W < rem ? s * W : rem;
+    base += take;
+    rem -= take;
+  }
+  int s = (rem + 2 * W - 1) / (2 * W);
+  s = s < 1 ? 1 : s;
+  const long long lb = (long long)i * s;
+  if (lb >= rem) {
+    b = e = n_tiles;
+    return;
+  }
+  b = base + (int)lb;
+  e = (lb + s < rem) ? b + s : base + rem;
+}
+
 // Stream order = consumption order.  Chunk (blk, mb):
 //   fragments  0..31 : fc_0 rows of block mb (tiles 2mb, 2mb+1): q = 4 ks + 2 tt + s
 //   fragments 32..63 : fc_1 columns of slab mb (k-step mb) for the 16 output tiles: q = 2 t + s
@@ -261,9 +298,10 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
     const int *__restrict__ tile_src, const half8 *__restrict__ packed, const float *__restrict__ fc_p_w,
     const float *__restrict__ table, const float *__restrict__ fc_out_w, float fc_out_b,
     float *__restrict__ logits, unsigned *status, int tiles_per_wg, const int *__restrict__ lin,
-    float *__restrict__ values, unsigned char *__restrict__ pstate, size_t n_per) {
+    float *__restrict__ values, unsigned char *__restrict__ pstate, size_t n_per, unsigned *claim) {
   constexpr bool X3 = TERMS == 3;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  __shared__ int s_claim;
   float *s_tab = reinterpret_cast<float *>(smem);
   float *s_wp = s_tab + ROWS * H;
   float *s_wo = s_wp + H * 3;
@@ -281,14 +319,39 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 
-  const int t_begin = blockIdx.x * tiles_per_wg;
-  const int t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
+  // claim != nullptr: chunks handed out dynamically (see chunk_range); nullptr: rounds 1-3's static partition
+  // (RFD_DECODER_STATIC=1, kept as the A/B control)
+  // thread index re-derived from the wave id (scalar) and mbcnt in the rare paths, so that threadIdx.x is not one more
+  // value held in a vector register (= spilled: the kernel runs at the 256-register limit) for the whole kernel
+  // (volatile: recomputed where it is used, never hoisted out of the tile loop and held)
+  auto tid = [&]() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return wave * 64 + l;
+  };
+  auto next_chunk = [&](int &b, int &e) {
+    if (tid() == 0) s_claim = (int)atomicAdd(claim, 1u);
+    __syncthreads();
+    const int k = __builtin_amdgcn_readfirstlane(s_claim);
+    __syncthreads();                      // everybody has read s_claim before thread 0 can overwrite it
+    chunk_range(k, n_tiles, (int)gridDim.x, b, e);
+  };
+  int t_begin, t_end;
+  if (claim) {
+    next_chunk(t_begin, t_end);
+  } else {
+    t_begin = blockIdx.x * tiles_per_wg;
+    t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
+  }
   int cur_prop = -1;
   bool ring_primed = false;
+  while (t_begin < t_end) {
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int prop = tile_prop[tile];
     if (prop < 0) continue;
-    const bool has_next = tile + 1 < t_end;
+    // the weight stream is the same for every tile, so the tail of a tile always fetches the first halves of "the
+    // next tile" when chunks are claimed (whichever tile that will be; a workgroup's last prefetch is simply not used)
+    const bool has_next = claim != nullptr || tile + 1 < t_end;
     const size_t pidx = (size_t)tile * TILE + wave * 16 + n;
     const size_t sidx = (size_t)(tile_src ? tile_src[tile] : tile) * TILE + wave * 16 + n;
     const float px = pts[sidx * 3 + 0], py = pts[sidx * 3 + 1], pz = pts[sidx * 3 + 2];
@@ -301,9 +364,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
       __syncthreads();
       const f32x4 *src = reinterpret_cast<const f32x4 *>(table + (size_t)prop * ROWS * H);
       f32x4 *dst = reinterpret_cast<f32x4 *>(s_tab);
-      for (int i = t; i < ROWS * H / 4; i += 512) dst[i] = src[i];
+      for (int i = tid(); i < ROWS * H / 4; i += 512) dst[i] = src[i];
       if (!ring_primed) {
-        int tt = t;
+        int tt = tid();
         asm volatile("" : "+v"(tt));     // once per kernel: keep these two per-lane addresses from being hoisted out of
                                          // the tile loop and held (spilled) for its whole duration
         for (int i = tt; i < H * 3; i += 512) s_wp[i] = fc_p_w[i];
@@ -572,10 +635,32 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
       }
     }
   }
+    if (!claim) break;
+    next_chunk(t_begin, t_end);
+  }
   if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(status, 2u);
+  if (claim) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last tile's unused ring prefetch has landed
+    if (tid() == 0) {
+      // every workgroup's last (failed) claim precedes its increment of claim[1]: the last one out resets the pair
+      __threadfence();
+      if (atomicAdd(claim + 1, 1u) == gridDim.x - 1) {
+        __atomic_store_n(claim, 0u, __ATOMIC_RELAXED);
+        __atomic_store_n(claim + 1, 0u, __ATOMIC_RELAXED);
+      }
+    }
+  }
 }
 
 }  // namespace
+
+// The chunk schedule of the eight-wave decoder as the host sees it (tests/test_chunk_schedule.py: the chunks of a launch
+// partition [0, n_tiles) for every grid size).
+RFD_API int rfd_occ_chunk_range(int k, int n_tiles, int n_workgroups, int *begin, int *end) {
+  if (k < 0 || n_tiles < 0 || n_workgroups <= 0 || !begin || !end) return (int)hipErrorInvalidValue;
+  chunk_range(k, n_tiles, n_workgroups, *begin, *end);
+  return 0;
+}
 
 RFD_API int rfd_occ_pack_weights_w8(const float *fc0_w, const float *fc1_w, const int *kw0, int kw1,
                                     void *packed, void *stream) {
@@ -601,16 +686,21 @@ static int decode_w8(int n_tiles, const float *pts, const int *tile_prop, const 
   // other CUs to whatever runs on other streams.  Measured: no gain, default = all.
   static const int cu_limit = getenv("RFD_DECODER_CUS") ? atoi(getenv("RFD_DECODER_CUS")) : 0;
   if (cu_limit > 0 && cu_limit < ncu) ncu = cu_limit;
+  // RFD_DECODER_STATIC=1: rounds 1-3's static partition (A/B control of the chunk claiming above)
+  // (read per launch: tests flip it inside one process)
+  const char *static_env = getenv("RFD_DECODER_STATIC");
+  const bool static_part = static_env && atoi(static_env) != 0;
   const int tiles_per_wg = ceil_div(n_tiles, ncu);
-  const int grid = ceil_div(n_tiles, tiles_per_wg);
+  const int grid = static_part ? ceil_div(n_tiles, tiles_per_wg) : (n_tiles < ncu ? n_tiles : ncu);
+  unsigned *claim = static_part ? nullptr : rfd_claim_pair(ws);
   if (mode == RFD_OCC_MODE_F16X3) {
     hipLaunchKernelGGL(occ_decode8_kernel<3>, dim3(grid), dim3(512), 0, s, n_tiles, pts, tile_prop, tile_src,
                        (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, rfd_status_word(ws, s), tiles_per_wg,
-                       lin, values, pstate, n_per);
+                       lin, values, pstate, n_per, claim);
   } else if (mode == RFD_OCC_MODE_F16X1) {
     hipLaunchKernelGGL(occ_decode8_kernel<1>, dim3(grid), dim3(512), 0, s, n_tiles, pts, tile_prop, tile_src,
                        (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, rfd_status_word(ws, s), tiles_per_wg,
-                       lin, values, pstate, n_per);
+                       lin, values, pstate, n_per, claim);
   } else {
     rfd_set_error("rfd_occ_decode_w8: unknown mode", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;

@@ -32,6 +32,9 @@ int rfd_get_workspace(RfdWorkspace **out) {
     for (int i = 0; i < RFD_STATUS_SLOTS; ++i) w->status_owner[i].store(nullptr);
     RFD_CHECK(hipMalloc((void **)&w->zeros, sizeof(float) * RFD_ZEROS_FLOATS));
     RFD_CHECK(hipMemset(w->zeros, 0, sizeof(float) * RFD_ZEROS_FLOATS));
+    RFD_CHECK(hipMalloc((void **)&w->claim, sizeof(unsigned) * 2 * RFD_CLAIM_SLOTS));
+    RFD_CHECK(hipMemset(w->claim, 0, sizeof(unsigned) * 2 * RFD_CLAIM_SLOTS));
+    w->claim_seq.store(0);
     w->ring_pos.store(0);
     w->num_cu = 0;
     (void)hipDeviceGetAttribute(&w->num_cu, hipDeviceAttributeMultiprocessorCount, dev);

@@ -103,7 +103,7 @@ class Generator3D(object):
             tile_prop = torch.arange(K, dtype=torch.int32, device=dev).repeat_interleave(tiles_per)
             tile_src = torch.arange(tiles_per, dtype=torch.int32, device=dev).repeat(K)
             logits = dec.decode_tiles(pts, tile_prop, table, fc_p_w, tile_src=tile_src)
-            self.stats = {'n_queries': K * total, 'rounds': 1}
+            self.stats = {'n_queries': K * total, 'rounds': 1, 'per_round': [K * total]}
             return logits.view(K, tiles_per * TILE)[:, :total].reshape(K, nx, nx, nx)
         return self._grids_mise(dec, table, fc_p_w, K, dev, box_size)
 
@@ -120,6 +120,7 @@ class Generator3D(object):
         _call("rfd_mise_init", dev, K, res0, depth, pstate.data_ptr(), vstate.data_ptr())
         thr = self.logit_threshold()
         n_queries, rounds = 0, 0
+        per_round = []                      # real query points of each round (the rounds of generator.py:99-117)
         while True:
             shared = rounds == 0 and self._round0(res0, depth, box_size, K, dev)
             if shared:
@@ -159,9 +160,10 @@ class Generator3D(object):
             _call("rfd_mise_subdivide", dev, K, res0, depth, float(thr), values.data_ptr(),
                   pstate.data_ptr(), vstate.data_ptr())
             n_queries += total
+            per_round.append(total)
             rounds += 1
         _call("rfd_mise_to_dense", dev, K, res0, depth, values.data_ptr(), pstate.data_ptr())
-        self.stats = {'n_queries': n_queries, 'rounds': rounds}
+        self.stats = {'n_queries': n_queries, 'rounds': rounds, 'per_round': per_round}
         return values.view(K, R1, R1, R1)
 
     def _round0(self, res0, depth, box_size, K, dev):

@@ -1,0 +1,56 @@
+"""CPU: the eight-wave decoder's run-time tile schedule (csrc/occ_decoder8.hip chunk_range, exported as
+rfd_occ_chunk_range -- pure host arithmetic, no GPU): for every launch size and grid size the chunks partition
+[0, n_tiles) in order, without gaps or overlaps; the first batch is half of the launch in equal chunks, the last
+chunks are single tiles (the kernel's tail is one tile), and past the last chunk the range is empty.
+
+The reference walks proposals and <=100 000-point slices one after the other (generator.py:71-74, 129-141); how the
+tiles of ONE launch are spread over the chip has no counterpart there -- results do not depend on it
+(tests/test_gpu_decoder.py compares claimed vs static launches bit for bit)."""
+import ctypes as C
+
+import pytest
+
+
+def _ranges(lib, n, W):
+    out, k = [], 0
+    b, e = C.c_int(), C.c_int()
+    while True:
+        assert lib.rfd_occ_chunk_range(k, n, W, C.byref(b), C.byref(e)) == 0
+        if b.value >= n:
+            assert b.value == e.value == n
+            break
+        out.append((b.value, e.value))
+        k += 1
+        assert k < 10 * W + 100000
+    # a few indices past the end stay empty (late workgroups' failed claims)
+    for kk in (k, k + 1, k + W, k + 7 * W + 3):
+        lib.rfd_occ_chunk_range(kk, n, W, C.byref(b), C.byref(e))
+        assert b.value == e.value == n, (kk, b.value, e.value)
+    return out
+
+
+@pytest.mark.parametrize("n,W", [(1, 256), (5, 256), (255, 256), (256, 256), (257, 256), (11327, 256), (11327, 252),
+                                 (71936, 256), (71936, 244), (524288, 256), (1000, 1), (1000, 3), (2 ** 24, 256)])
+def test_chunks_partition_the_launch(n, W):
+    from rfdnet_amd import _lib
+    lib = _lib.lib()
+    r = _ranges(lib, n, W)
+    assert r[0][0] == 0 and r[-1][1] == n
+    for (b0, e0), (b1, e1) in zip(r, r[1:]):
+        assert e0 == b1 and b0 < e0
+    sizes = [e - b for b, e in r]
+    assert sizes == sorted(sizes, reverse=True) or n < 2 * W     # never growing (a partial batch may end short)
+    assert sizes[-1] == 1 or len(r) <= W                          # tail = single tiles once there is more than one batch
+    if n >= 4 * W:
+        first = sizes[:W]
+        assert len(set(first)) == 1 and abs(sum(first) - n / 2) <= W     # first batch: half of the launch, equal chunks
+        # ~log2 chunks per workgroup: few conditioning-table loads
+        assert len(r) <= W * 20
+
+
+def test_bad_arguments_are_refused():
+    from rfdnet_amd import _lib
+    lib = _lib.lib()
+    b, e = C.c_int(), C.c_int()
+    assert lib.rfd_occ_chunk_range(-1, 10, 4, C.byref(b), C.byref(e)) != 0
+    assert lib.rfd_occ_chunk_range(0, 10, 0, C.byref(b), C.byref(e)) != 0

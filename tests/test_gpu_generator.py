@@ -286,3 +286,45 @@ def test_generate_mesh_end_to_end_scaling(hip, onet_and_fixture):
         onlat = np.abs(u - np.round(u)) < 1e-6
         assert (onlat.sum(1) >= 2).all()
         assert int(m.faces.max()) < v.shape[0]
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.5, 5.0, 5.6, 6.5])
+def test_mise_path_in_the_logit_bands_of_a_trained_checkpoint(hip, oracle, onet_and_fixture, scale):
+    """The logit bands of tests/test_gpu_decoder.py once through the whole MISE loop (generator.py:99-117): conditioning
+    codes scaled so that |logit| reaches ~1 / 3 / 10 / 30, fc_out.bias shifted so that the threshold cuts through the
+    middle of each proposal-0 field (otherwise the scaled fields are one-signed and MISE never refines); HIP value grids
+    against the CPU path (oracle decoder -> octree oracle, oracle/parity.py).  A decision may flip only where the field
+    is within fp32 noise of the threshold."""
+    from collections import OrderedDict
+    from oracle import parity
+    fx = onet_and_fixture
+    res0, steps = 16, 1
+    onet = load_onet_seeded(make_onet(res0, steps), fx)
+    gen = onet.generator
+    thr = gen.logit_threshold()
+    codes_h = (fx["codes"] * np.float32(scale)).astype(np.float32)
+    z = onet.get_z_from_prior((codes_h.shape[0],), sample=gen.sample, device="cpu").numpy()
+    state = lambda: OrderedDict((k, v.detach().cpu().numpy()) for k, v in onet.decoder.state_dict().items())
+    lattice = oracle.make_3d_grid(-0.5, 0.5, res0 + 1, 1.0 + gen.padding)
+    level0 = oracle.decoder_cbn(oracle.decoder_param_blob(state()), lattice[None], z[:1], codes_h[:1])
+    with torch.no_grad():
+        onet.decoder.fc_out.bias.sub_(float(np.median(level0)) - thr)
+    blob = oracle.decoder_param_blob(state())
+    codes = torch.from_numpy(codes_h).cuda()
+    grids = gen.generate_grids(codes, None).cpu().numpy()
+    hip.device_status()
+    flips = near = queries = 0
+    worst = top = 0.0
+    for k in range(codes.shape[0]):
+        cpu_grid, n_q = parity.cpu_value_grid(blob, z[k], codes_h[k], res0, steps, thr, gen.padding)
+        queries += n_q
+        flips += int(((grids[k] >= thr) != (cpu_grid >= thr)).sum())
+        near += int((np.abs(cpu_grid - thr) < 1e-4).sum())
+        worst = max(worst, float(np.abs(grids[k] - cpu_grid).max()))
+        top = max(top, float(np.abs(cpu_grid).max()))
+    assert queries == gen.stats['n_queries'] or flips, (queries, gen.stats)
+    print("codes x%.1f: |logit| up to %.1f, %d query points, max |HIP grid - CPU grid| %.2e, %d flipped decisions "
+          "(%d points within 1e-4 of the threshold)" % (scale, top, queries, worst, flips, near))
+    assert flips <= max(1, near)
+    # fp32 noise of the oracle itself grows with the activations (tests/test_gpu_decoder.py bands): 1e-4 up to |logit| 10
+    assert worst <= (1e-4 if top <= 10 else 1e-5 * top)
