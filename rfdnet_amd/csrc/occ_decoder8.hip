@@ -56,6 +56,25 @@
 #ifndef DEC8_WLO_BITS
 #define DEC8_WLO_BITS 11
 #endif
+// Round 4 energy ledger (profiles/r04_decoder_energy.txt), timing-only side builds on REAL (non-zero) operands:
+//   DEC8_THIN  1 = weight-fragment LDS reads thinned to 1/8: every k-step of an 8-step sequence reuses the registers
+//              of its k-step 0 (results wrong; separates LDS-read stalls + energy from multiplier energy)
+//   DEC8_BF16C 2 = both correction products (W_hi x a_lo, W_lo x a_hi) issued as v_mfma_f32_16x16x32_bf16 on the same
+//              register bits (W_lo packed as bf16 values), 1 = W_lo x a_hi only; prices 8-bit against 11-bit
+//              significands in the multiplier arrays.  f16 bits read as bf16 can be huge, so the re-typed products go
+//              to two JUNK accumulators instead of the data path (a NaN would be rectified to 0 and zero the
+//              operands of every later layer); the data path keeps the hi x hi term.  Results wrong on purpose.
+//   DEC8_JUNK  1 = control of the above: the corrections stay f16 MFMAs but also go to the junk accumulators (same
+//              dependency structure as DEC8_BF16C 2, shipped arithmetic types)
+#ifndef DEC8_THIN
+#define DEC8_THIN 0
+#endif
+#ifndef DEC8_BF16C
+#define DEC8_BF16C 0
+#endif
+#ifndef DEC8_JUNK
+#define DEC8_JUNK 0
+#endif
 
 namespace {
 
@@ -160,12 +179,27 @@ __global__ void pack8_kernel(const float *__restrict__ fc0_w, const float *__res
     lo = __builtin_bit_cast(_Float16, b);
   }
 #endif
+#if DEC8_BF16C
+  if (s != 0) {          // W_lo as bf16 (round to nearest even on the fp32 bit pattern)
+    const float r = w - (float)hi;
+    unsigned u = __builtin_bit_cast(unsigned, r);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    reinterpret_cast<unsigned short *>(packed)[e] = (unsigned short)(u >> 16);
+    return;
+  }
+#endif
   packed[e] = s == 0 ? hi : lo;
 }
 
 __device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+#if DEC8_BF16C
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16b(half8 a, half8 b, f32x4 c) {       // the same registers read as bf16
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+#endif
 
 __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
   unsigned r;
@@ -311,6 +345,30 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g4 = 4 * (lane >> 4), n = lane & 15;
   unsigned amax16 = 0u;
+  // the two correction products of the three-term scheme; `ch` = which of the two interleaved accumulator chains
+#if DEC8_BF16C || DEC8_JUNK
+  f32x4 junk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#endif
+  auto corr_hl = [&](f32x4 &acc, int ch, const half8 &wh, const half8 &xl) {      // W_hi x a_lo
+#if DEC8_BF16C == 2
+    junk[ch] = mfma16b(wh, xl, junk[ch]);
+#elif DEC8_JUNK
+    junk[ch] = mfma16(wh, xl, junk[ch]);
+#else
+    (void)ch;
+    acc = mfma16(wh, xl, acc);
+#endif
+  };
+  auto corr_lh = [&](f32x4 &acc, int ch, const half8 &wl, const half8 &xh) {      // W_lo x a_hi
+#if DEC8_BF16C
+    junk[ch] = mfma16b(wl, xh, junk[ch]);
+#elif DEC8_JUNK
+    junk[ch] = mfma16(wl, xh, junk[ch]);
+#else
+    (void)ch;
+    acc = mfma16(wl, xh, acc);
+#endif
+  };
   // NO static priority in the shipped build, and tests/test_isa_audit.py refuses one: unequal priorities of a SIMD's
   // two waves are the one necessary condition of round 2's wrong 16-point groups that is understood (the rest is code
   // layout and the timing of the partner wave's path: profiles/r03_decoder_hazard.txt sections 7-9), and they buy nothing
@@ -415,16 +473,19 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           constexpr int ks = decltype(kc)::value;
           Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
           step_fence();
-          if constexpr (ks < 7) frag_issue<4096 * (ks + 1)>(nxt, a0);
+          if constexpr (ks < 7) {
+            if (DEC8_THIN) nxt = cur;
+            else frag_issue<4096 * (ks + 1)>(nxt, a0);
+          }
           if constexpr (ks < 7)
             act_kstep<X3>(Hs[2 * ks + 2], Hs[2 * ks + 3], S0, T0, 32 * (ks + 1) + g4, ahi[ks + 1], alo[ks + 1], amax16);
           acc_cur[0] = mfma16(cur.h0, ahi[ks], acc_cur[0]);
           acc_cur[1] = mfma16(cur.h1, ahi[ks], acc_cur[1]);
           if (X3) {
-            acc_cur[0] = mfma16(cur.h0, alo[ks], acc_cur[0]);
-            acc_cur[1] = mfma16(cur.h1, alo[ks], acc_cur[1]);
-            acc_cur[0] = mfma16(cur.l0, ahi[ks], acc_cur[0]);
-            acc_cur[1] = mfma16(cur.l1, ahi[ks], acc_cur[1]);
+            corr_hl(acc_cur[0], 0, cur.h0, alo[ks]);
+            corr_hl(acc_cur[1], 1, cur.h1, alo[ks]);
+            corr_lh(acc_cur[0], 0, cur.l0, ahi[ks]);
+            corr_lh(acc_cur[1], 1, cur.l1, ahi[ks]);
           }
           if constexpr (ks == 0) keep_alive(cur);
           else keep_alive(cur, prv);
@@ -491,16 +552,20 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
             constexpr int ks = decltype(kc)::value;
             Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
             step_fence();
-            if constexpr (ks < 7) frag_issue<4096 * (ks + 1)>(nxt, aA);
-            else frag_issue<0>(nxt, aB);
+            if constexpr (ks < 7) {
+              if (DEC8_THIN) nxt = cur;
+              else frag_issue<4096 * (ks + 1)>(nxt, aA);
+            } else {
+              frag_issue<0>(nxt, aB);
+            }
             issue_dma(ks);
             acc_next[0] = mfma16(cur.h0, ahi[ks], acc_next[0]);
             acc_next[1] = mfma16(cur.h1, ahi[ks], acc_next[1]);
             if (X3) {
-              acc_next[0] = mfma16(cur.h0, alo[ks], acc_next[0]);
-              acc_next[1] = mfma16(cur.h1, alo[ks], acc_next[1]);
-              acc_next[0] = mfma16(cur.l0, ahi[ks], acc_next[0]);
-              acc_next[1] = mfma16(cur.l1, ahi[ks], acc_next[1]);
+              corr_hl(acc_next[0], 0, cur.h0, alo[ks]);
+              corr_hl(acc_next[1], 1, cur.h1, alo[ks]);
+              corr_lh(acc_next[0], 0, cur.l0, ahi[ks]);
+              corr_lh(acc_next[1], 1, cur.l1, ahi[ks]);
             }
             if constexpr (ks == 0) keep_alive(cur);
             else keep_alive(cur, prv);
@@ -515,14 +580,17 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           constexpr int ks = 8 + tp;
           Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
           step_fence();
-          if constexpr (tp < 7) frag_issue<4096 * (tp + 1)>(nxt, aB);
+          if constexpr (tp < 7) {
+            if (DEC8_THIN) nxt = cur;
+            else frag_issue<4096 * (tp + 1)>(nxt, aB);
+          }
           Hs[2 * tp] = mfma16(cur.h0, bhi, Hs[2 * tp]);
           Hs[2 * tp + 1] = mfma16(cur.h1, bhi, Hs[2 * tp + 1]);
           if (X3) {
-            Hs[2 * tp] = mfma16(cur.h0, blo, Hs[2 * tp]);
-            Hs[2 * tp + 1] = mfma16(cur.h1, blo, Hs[2 * tp + 1]);
-            Hs[2 * tp] = mfma16(cur.l0, bhi, Hs[2 * tp]);
-            Hs[2 * tp + 1] = mfma16(cur.l1, bhi, Hs[2 * tp + 1]);
+            corr_hl(Hs[2 * tp], 0, cur.h0, blo);
+            corr_hl(Hs[2 * tp + 1], 1, cur.h1, blo);
+            corr_lh(Hs[2 * tp], 0, cur.l0, bhi);
+            corr_lh(Hs[2 * tp + 1], 1, cur.l1, bhi);
           }
           // tp == 0: the set before this one is phase A's step 7 (mb < 7) or nothing (mb == 7, behind a barrier)
           if constexpr (tp == 0) {
@@ -639,6 +707,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
     next_chunk(t_begin, t_end);
   }
   if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(status, 2u);
+#if DEC8_BF16C || DEC8_JUNK
+  asm volatile("" ::"v"(junk[0]), "v"(junk[1]));
+#endif
   if (claim) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last tile's unused ring prefetch has landed
     if (tid() == 0) {

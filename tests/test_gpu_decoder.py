@@ -262,12 +262,12 @@ def test_claimed_chunks_through_the_fused_scatter(hip):
 
 
 # ------------------------------------------------------------------ logit bands (round 4) ----
-BANDS = [  # (name, conditioning scale, fc_out scale)
-    ("+-3 (fc_out x4)", 1.0, 4.0),
-    ("+-3 (codes x3.5)", 3.5, 1.0),
-    ("+-10 (codes x5)", 5.0, 1.0),
-    ("+-30 (codes x5.6)", 5.6, 1.0),
-    ("+-50 (codes x6)", 6.0, 1.0),
+BANDS = [  # (name, conditioning scale, fc_out scale, absolute tolerance or None)
+    ("+-3 (fc_out x4)", 1.0, 4.0, LOGIT_TOL),
+    ("+-3 (codes x3.5)", 3.5, 1.0, LOGIT_TOL),
+    ("+-10 (codes x5)", 5.0, 1.0, LOGIT_TOL),
+    ("+-30 (codes x5.6)", 5.6, 1.0, LOGIT_TOL),
+    ("+-50 (codes x6)", 6.0, 1.0, None),       # beyond the band a checkpoint lives in: relative bound only
 ]
 
 
@@ -291,11 +291,14 @@ def test_decoder_logit_bands_where_a_trained_checkpoint_lives(hip, oracle):
     restated in float64 (tests/dec_f64.py); the fp32 oracle (module semantics, k-ascending sums) is measured against
     it too, because at |logit| ~ 30 one fp32 evaluation of the module is itself 1.4e-4 from the exact value (measured
     in the build container) -- so |HIP - oracle| <= 1e-4 cannot hold there for ANY implementation, the reference on
-    another BLAS included.  Asserted per band and kernel:  |HIP - exact| <= 1e-4;  |HIP - oracle| <= 1e-4 + the
-    oracle's own distance from exact;  HIP at least as close to exact as the fp32 evaluation (x1.25 + 2e-6 slack)."""
+    another BLAS included.  Asserted per band and kernel:  |HIP - exact| <= 1e-4 up to the +-30 band (measured on MI355X
+    at +-50: 1.55e-4 for the kernel, 1.94e-4 for the fp32 oracle -- there only the relative bound 4e-6 of max |logit|
+    is asserted);  |HIP - oracle| <= 1e-4 + the oracle's own distance from exact;  HIP at least as close to exact as
+    the fp32 evaluation (x1.25 + 2e-6 slack) -- i.e. fp32-class in every band."""
     from dec_f64 import decoder_f64
     lines = ["band                 kernel  |logit|max  act max   |HIP-f64|   |oracle32-f64|  |HIP-oracle32|"]
-    for name, cs, fs in BANDS:
+    failures = []
+    for name, cs, fs, tol in BANDS:
         for kern in ("w8", "w4"):
             dec, sd, p, z, c = _band_case(cs, fs)
             dec.kernel = kern
@@ -309,14 +312,19 @@ def test_decoder_logit_bands_where_a_trained_checkpoint_lives(hip, oracle):
             e_hip, e_or, e_ho = np.abs(o - exact).max(), np.abs(ref32 - exact).max(), np.abs(o - ref32).max()
             lines.append("%-20s %-6s  %9.2f  %7.1f   %.2e    %.2e        %.2e"
                          % (name, kern, np.abs(exact).max(), amax, e_hip, e_or, e_ho))
-            assert e_hip <= LOGIT_TOL, (name, kern, e_hip)
-            assert e_ho <= LOGIT_TOL + e_or, (name, kern, e_ho, e_or)
-            assert e_hip <= 1.25 * e_or + 2e-6, (name, kern, e_hip, e_or)
+            top = np.abs(exact).max()
+            if not e_hip <= (tol if tol is not None else 4e-6 * top):
+                failures.append(("|HIP - exact|", name, kern, e_hip))
+            if not e_ho <= (tol if tol is not None else 4e-6 * top) + e_or:
+                failures.append(("|HIP - oracle|", name, kern, e_ho, e_or))
+            if not e_hip <= 1.25 * e_or + 2e-6:
+                failures.append(("HIP further from exact than the fp32 oracle", name, kern, e_hip, e_or))
     print("\n".join(lines))
     out_dir = os.environ.get("RFD_BANDS_OUT")
     if out_dir:
         with open(out_dir, "w") as fh:
             fh.write("\n".join(lines) + "\n")
+    assert not failures, failures
 
 
 def test_decoder_logit_band_beyond_the_default_scale(hip, oracle):
