@@ -313,18 +313,28 @@ def test_mise_path_in_the_logit_bands_of_a_trained_checkpoint(hip, oracle, onet_
     codes = torch.from_numpy(codes_h).cuda()
     grids = gen.generate_grids(codes, None).cpu().numpy()
     hip.device_status()
-    flips = near = queries = 0
+    flips = near = queries = off = 0
     worst = top = 0.0
+    cpu = []
     for k in range(codes.shape[0]):
         cpu_grid, n_q = parity.cpu_value_grid(blob, z[k], codes_h[k], res0, steps, thr, gen.padding)
+        cpu.append(cpu_grid)
         queries += n_q
+        top = max(top, float(np.abs(cpu_grid).max()))
+    # fp32 noise of the oracle itself grows with the activations (tests/test_gpu_decoder.py bands): 1e-4 up to |logit| 10
+    tol = 1e-4 if top <= 10 else 1e-5 * top
+    for k, cpu_grid in enumerate(cpu):
         flips += int(((grids[k] >= thr) != (cpu_grid >= thr)).sum())
         near += int((np.abs(cpu_grid - thr) < 1e-4).sum())
-        worst = max(worst, float(np.abs(grids[k] - cpu_grid).max()))
-        top = max(top, float(np.abs(cpu_grid).max()))
-    assert queries == gen.stats['n_queries'] or flips, (queries, gen.stats)
-    print("codes x%.1f: |logit| up to %.1f, %d query points, max |HIP grid - CPU grid| %.2e, %d flipped decisions "
-          "(%d points within 1e-4 of the threshold)" % (scale, top, queries, worst, flips, near))
+        d = np.abs(grids[k] - cpu_grid)
+        off += int((d > tol).sum())
+        worst = max(worst, float(d[d <= tol].max()))
+    print("codes x%.1f: |logit| up to %.1f, %d query points (HIP %d), max |HIP grid - CPU grid| %.2e over the points "
+          "within %.0e, %d points beyond it, %d flipped decisions (%d points within 1e-4 of the threshold)"
+          % (scale, top, queries, gen.stats['n_queries'], worst, tol, off, flips, near))
+    # MISE is data dependent: a value within fp32 noise of the threshold may flip ONE subdivision, and then up to 27 fine
+    # points of that coarse voxel are evaluated on one side and filled from the coarser level on the other (observed on
+    # MI355X at codes x6.5: 1 flip with 2 points within 1e-4 of the threshold; none in the other bands)
     assert flips <= max(1, near)
-    # fp32 noise of the oracle itself grows with the activations (tests/test_gpu_decoder.py bands): 1e-4 up to |logit| 10
-    assert worst <= (1e-4 if top <= 10 else 1e-5 * top)
+    assert off <= 27 * min(flips, near), (off, flips, near)
+    assert queries == gen.stats['n_queries'] or flips
