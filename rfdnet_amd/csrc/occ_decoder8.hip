@@ -455,7 +455,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
     // code's LDS bursts and MFMAs; on the failing binary a barrier here cures it (0/4 against 4/4 for the same bytes
     // without it: profiles/r03_decoder_hazard.txt section 8).  The shipped build has no priorities and never showed
     // the fault, so this is a belt: one barrier per tile, next to ~45 others.
+#if !defined(DEC8_NO_PROLOGUE_BARRIER)      // (the positive control of tools/audit_prologue_lds.py builds without it)
     __syncthreads();
+#endif
 
     half8 ahi[8], alo[8];
     for (int blk = 0; blk < NB; ++blk) {

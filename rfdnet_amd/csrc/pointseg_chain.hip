@@ -228,6 +228,12 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a) {
           h1lo[0] = inlo[0]; h1lo[1] = inlo[1];
         }
       }
+      // MODE 1: the first layer above is a VALU prologue on LDS-loaded weights (ds_read -> v_mov / v_pk_fma, ~130
+      // consumers) running straight into MFMA code -- the shape of the decoder's tile prologue, the one place where round
+      // 2's static-priority build lost an LDS-loaded value while the SIMD partner was already in its MFMA code
+      // (profiles/r03_fault_model.txt).  Same belt as there: all eight waves finish it before any enters the MFMAs
+      // (tools/audit_prologue_lds.py finds the shape; tests/test_isa_audit.py asserts it is gone).  Uniform control flow.
+      if (MODE == 1) __syncthreads();
       // ---- 64 -> 128
       __builtin_amdgcn_sched_barrier(0);
       f32x4 d2[8];
@@ -477,6 +483,9 @@ __global__ __launch_bounds__(512) void head_kernel(HeadArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
       act_pair(H2[2 * ks], H2[2 * ks + 1], s_bb, 32 * ks + g4, a.osb, a.ascale, chi[ks], clo[ks], amax16);
+    // 48 VALU consumers of LDS-read bias rows with no MFMA since the last barrier, layer c's MFMAs right behind: closed
+    // with a barrier like the decoder's tile prologue (tools/audit_prologue_lds.py); one per 128-point pass
+    __syncthreads();
     float sc0 = 0.f, sc1 = 0.f;
     for (int i = 0; i < H_CPIECES; ++i) {
       const int p = pass * H_PIECES + H_SLABS + i;

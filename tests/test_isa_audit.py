@@ -96,3 +96,36 @@ def test_no_kernel_runs_its_waves_at_unequal_priorities(tmp_path):
             report.append("%s %s: %d MFMAs, %d loads, closest load to an MFMA source: %s MFMAs, findings %d"
                           % (src, k, st['mfma'], st['loads'], st['min_ab_gap'], len(problems)))
     print("\n".join(report))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
+                    reason="hipcc not available")
+def test_no_two_wave_kernel_runs_a_valu_prologue_on_lds_reads_into_mfma_code_without_a_barrier(tmp_path):
+    """The one code shape round 3's fault model names (profiles/r03_fault_model.txt): a long VALU prologue consuming
+    LDS-read registers (fc_p of the decoder's tile: ~130 consumers, v_mov / v_pk_fma out of ds_read_b128) that runs
+    into MFMA code with no s_barrier, so the SIMD partner can be in its MFMAs while this wave still reads.
+    tools/audit_prologue_lds.py (control-flow-graph data flow over the generated assembly) must find NO such region in
+    any kernel that runs two waves per SIMD -- round 4 found and closed two (chain_kernel<1>'s VALU first layer,
+    head_kernel's 256-wide rectification) -- and must FIND the decoder's own when its barrier is compiled out (the
+    positive control).  The short phase-entry stretches of the steady state are counted and printed, not refused."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_prologue_lds
+    report = []
+    for src, kernels in (("occ_decoder8.hip", ["occ_decode8_kernelILi3E", "occ_decode8_kernelILi1E"]),
+                         ("pointseg_chain.hip", ["chain_kernelILi0E", "chain_kernelILi1E", "chain_kernelILi2E", "head_kernel"]),
+                         ("gemm_f16x3.hip", ["gemm_rows8_kernelILb1ELb0E", "gemm_rows8_kernelILb1ELb1E",
+                                             "gemm_rows8_kernelILb0ELb0E", "gemm_rows8_kernelILb0ELb1E", "gemm_f16x3_kernel"]),
+                         ("sa_fused.hip", ["sa_fused_kernelILi4E"])):
+        asm = _asm(tmp_path, src, src + ".pl.s")
+        for k in kernels:
+            st, found = audit_prologue_lds.audit(asm, k)
+            assert st['mfma'] > 0 and st['ds_reads'] > 0, (src, k, st)
+            report.append("%s %s: %s; %d LDS->VALU consumers at phase entries (not refused)"
+                          % (src, k, "none" if not found else "%d consumers in a prologue-class region" % len(found),
+                             st['phase_entry_consumers']))
+            assert found == [], (src, k, found[:3])
+    control = _asm(tmp_path, "occ_decoder8.hip", "dec8_nobar.s", ("-DDEC8_NO_PROLOGUE_BARRIER",))
+    st, found = audit_prologue_lds.audit(control, "occ_decode8_kernelILi3E")
+    assert len(found) >= 64, (st, len(found))
+    report.append("control (decoder tile prologue without its barrier): %d consumers flagged" % len(found))
+    print("\n".join(report))
