@@ -11,7 +11,7 @@ Recipe = SURVEY.md Appendix A: bare namespace packages so models/__init__.py
 replaced by the CPU oracle, absent third-party deps stubbed, MISE built from
 the reference's mise.pyx with Cython in a scratch directory.
 
-Usage:  python tests/golden/make_fixtures.py [dec] [mise] [grid] [ops] [net] [gen] [nms] [cd] [fit] [mc]
+Usage:  python tests/golden/make_fixtures.py [dec] [mise] [grid] [ops] [net] [net80k] [gen] [nms] [cd] [fit] [mc]
 """
 import importlib
 import os
@@ -241,6 +241,64 @@ def make_net():
         out['skip_codes'] = codes.numpy()
     np.savez_compressed(os.path.join(HERE, "F_NET.npz"), **out)
     print("F_NET ok", {k: v.shape for k, v in out.items() if not k.endswith(('names', 'shapes'))})
+
+
+def make_net80k():
+    """F-NET80k (round 4): the same three reference modules (pointnet2backbone.py:75-125, vote_module.py,
+    proposal_module.py:85-124) on the oracle `_ext` at the size the metric is quoted on -- the headline scene, 80 000
+    points (seed 10, 120 000 raw).  Kept: every index tensor, the sampled coordinates, and a 64-point sample of each
+    feature tensor (evenly spaced points, all channels) -- < 1 MB."""
+    import torch
+    mount_reference()
+    from rfdnet_amd.iscnet.config import Config
+    cfg = Config({'data': {'num_point': 80000}})
+    ns('models.registers')
+    reg = importlib.import_module('net_utils.registry')
+    sys.modules['models.registers'].MODULES = reg.Registry('module')
+    sys.modules['models.registers'].METHODS = reg.Registry('method')
+    sys.modules['models.registers'].LOSSES = reg.Registry('loss')
+    bbm = importlib.import_module('models.iscnet.modules.pointnet2backbone')
+    vm = importlib.import_module('models.iscnet.modules.vote_module')
+    pm = importlib.import_module('models.iscnet.modules.proposal_module')
+    out = {}
+    pc = synthetic.synthetic_scene(seed=10, n_raw=120000, n_points=80000)
+    out['pc_seed'] = np.array([10, 120000, 80000])
+    x = torch.from_numpy(pc[None])
+
+    def sample(t):                       # (1, C, n) -> (C, 64): 64 evenly spaced points, every channel
+        n = t.shape[2]
+        cols = np.linspace(0, n - 1, 64).astype(np.int64)
+        return np.ascontiguousarray(t.numpy()[0][:, cols]), cols.astype(np.int32)
+
+    with torch.no_grad():
+        bb = bbm.Pointnet2Backbone(cfg)
+        synthetic.load_seeded(bb, 101)
+        bb.eval()
+        ep = bb(x, {})
+        for k in ('sa1_inds', 'sa2_inds', 'fp2_inds'):
+            out['bb_' + k] = ep[k].numpy().astype(np.int32)
+        for k in ('sa1_xyz', 'sa2_xyz', 'sa3_xyz', 'sa4_xyz'):
+            out['bb_' + k] = ep[k].numpy()
+        for k in ('sa1_features', 'sa2_features', 'sa3_features', 'sa4_features', 'fp2_features'):
+            out['bb_' + k], out['bb_' + k + '_cols'] = sample(ep[k])
+        vote = vm.VotingModule(cfg)
+        synthetic.load_seeded(vote, 102)
+        vote.eval()
+        vxyz, vfeat = vote(ep['fp2_xyz'], ep['fp2_features'])
+        vfeat = vfeat.div(torch.norm(vfeat, p=2, dim=1).unsqueeze(1))      # demo.py:215-216
+        out['vote_xyz'] = vxyz.numpy()
+        out['vote_features'], out['vote_features_cols'] = sample(vfeat)
+        prop = pm.ProposalModule(cfg)
+        synthetic.load_seeded(prop, 103)
+        prop.eval()
+        ep['seed_xyz'] = ep['fp2_xyz']
+        ep, pf = prop(vxyz, vfeat, ep, True)
+        out['prop_aggregated_vote_inds'] = ep['aggregated_vote_inds'].numpy().astype(np.int32)
+        for k in ('aggregated_vote_xyz', 'center', 'objectness_scores', 'sem_cls_scores'):
+            out['prop_' + k] = ep[k].numpy()
+        out['prop_features'], out['prop_features_cols'] = sample(pf)
+    np.savez_compressed(os.path.join(HERE, "F_NET80k.npz"), **out)
+    print("F_NET80k ok", {k: v.shape for k, v in out.items()})
 
 
 def make_gen():

@@ -130,3 +130,54 @@ def test_sa_module_fused_path_equals_operator_composition(hip):
     out = qg(xyz, new_xyz, feats)[0]
     out.sum().backward()
     assert feats.grad is not None and float(feats.grad.abs().sum()) > 0
+
+
+def test_backbone_vote_proposal_at_the_size_the_metric_is_quoted_on(hip, golden_dir):
+    """F_NET80k (round 4): the reference's Pointnet2Backbone -> VotingModule -> ProposalModule
+    (pointnet2backbone.py:75-125, proposal_module.py:85-124), run in the build container on the oracle `_ext`, on the
+    HEADLINE scene -- 80 000 points, seed 10 -- against the HIP path: index tensors and sampled coordinates bit-equal,
+    a 64-point sample of every feature tensor (all channels) at fp32-class accuracy.  Removes the "4096 points only"
+    caveat of F_NET."""
+    from rfdnet_amd.iscnet.pointnet2backbone import Pointnet2Backbone
+    from rfdnet_amd.iscnet.proposal_module import ProposalModule
+    from rfdnet_amd.iscnet.vote_module import VotingModule
+    fx = np.load(os.path.join(golden_dir, "F_NET80k.npz"))
+    seed, n_raw, n_pts = (int(v) for v in fx["pc_seed"])
+    assert n_pts == 80000
+    pc = torch.from_numpy(synthetic.synthetic_scene(seed=seed, n_raw=n_raw, n_points=n_pts)[None]).cuda()
+    cfg = Config({'data': {'num_point': n_pts}})
+    with torch.no_grad():
+        bb = Pointnet2Backbone(cfg); synthetic.load_seeded(bb, 101); bb = bb.cuda().eval()
+        ep = bb(pc, {})
+        for k in ('sa1_inds', 'sa2_inds', 'fp2_inds'):
+            np.testing.assert_array_equal(ep[k].cpu().numpy(), fx['bb_' + k])
+        for k in ('sa1_xyz', 'sa2_xyz', 'sa3_xyz', 'sa4_xyz'):
+            np.testing.assert_array_equal(ep[k].cpu().numpy(), fx['bb_' + k])
+        for k in ('sa1_features', 'sa2_features', 'sa3_features', 'sa4_features', 'fp2_features'):
+            cols = torch.from_numpy(fx['bb_' + k + '_cols'].astype(np.int64)).cuda()
+            assert outliers('80k bb_' + k, ep[k][0][:, cols], fx['bb_' + k]) == 0, k
+        vote = VotingModule(cfg); synthetic.load_seeded(vote, 102); vote = vote.cuda().eval()
+        vxyz, vfeat = vote(ep['fp2_xyz'], ep['fp2_features'])
+        vfeat = vfeat.div(torch.norm(vfeat, p=2, dim=1).unsqueeze(1))
+        assert outliers('80k vote_xyz', vxyz, fx['vote_xyz']) == 0
+        cols = torch.from_numpy(fx['vote_features_cols'].astype(np.int64)).cuda()
+        assert outliers('80k vote_features', vfeat[0][:, cols], fx['vote_features']) == 0
+        prop = ProposalModule(cfg); synthetic.load_seeded(prop, 103); prop = prop.cuda().eval()
+        ep['seed_xyz'] = ep['fp2_xyz']
+        ep, pf = prop(vxyz, vfeat, ep, True)
+        np.testing.assert_array_equal(ep['aggregated_vote_inds'].cpu().numpy(), fx['prop_aggregated_vote_inds'])
+        # a vote within an ulp of a ball boundary may change one proposal's neighbourhood (see the 4096-point test):
+        # rows are fp32-class or counted as flipped
+        bad = np.zeros(256, bool)
+        for k in ('aggregated_vote_xyz', 'center', 'objectness_scores', 'sem_cls_scores'):
+            a = ep[k][0].cpu().numpy().astype(np.float64).reshape(256, -1)
+            b = fx['prop_' + k][0].astype(np.float64).reshape(256, -1)
+            outliers('80k prop_' + k, ep[k], fx['prop_' + k])
+            bad |= (np.abs(a - b) > 1e-5 * np.abs(b).max() + 1e-4 * np.abs(b)).any(axis=1)
+        cols = fx['prop_features_cols'].astype(np.int64)
+        a = pf[0][:, torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.float64)
+        b = fx['prop_features'].astype(np.float64)
+        outliers('80k prop_features', a, b)
+        bad[cols] |= (np.abs(a - b) > 1e-5 * np.abs(b).max() + 1e-4 * np.abs(b)).any(axis=0)
+        print("80k: proposal rows not at fp32 accuracy (neighbourhood flips): %d of 256 %s" % (int(bad.sum()), np.where(bad)[0]))
+        assert int(bad.sum()) <= 2
