@@ -111,7 +111,7 @@ class DecodeTimer(object):
         self.dec = dec
         self.records = []
         self.enabled = False
-        self.round = 0             # MISE round of the next launch (set by the generator's round hook)
+        self.local = threading.local()   # .round = MISE round of the calling worker's next launch (the round hook sets it)
         self._orig = dec.decode_tiles
 
         def wrapped(pts, tile_prop, *a, **k):
@@ -125,7 +125,7 @@ class DecodeTimer(object):
                 e1.record()
                 DecodeTimer.last_end = e1
             if self.enabled:
-                self.records.append((int(tile_prop.shape[0]) * 128, e0, e1, self.round))
+                self.records.append((int(tile_prop.shape[0]) * 128, e0, e1, getattr(self.local, "round", 0)))
             return out
         dec.decode_tiles = wrapped
 
@@ -196,8 +196,8 @@ class MeshSink(object):
 
 
 class HipBackend(object):
-    """The product path on one GPU: `in_flight` workers (model replica + HIP stream + mesh
-    sink + decoder timer each) over a pool of HBM-resident synthetic scenes."""
+    """The product path on one GPU: `in_flight` workers (HIP stream + mesh sink + a view of the ONE
+    read-only model with its own MISE / mesh state each) over a pool of HBM-resident synthetic scenes."""
 
     name = "hip"
 
@@ -218,8 +218,11 @@ class HipBackend(object):
         self.NB = max(1, args.batch)
         self.record_scenes, self.scene_records = False, []
         self.round_points = {}
-        self.nets = [self._build_net() for _ in range(self.S)]
-        self.timers = [DecodeTimer(n.completion.decoder) for n in self.nets]
+        # ONE set of weights / packed weight streams per GPU; every in-flight worker gets a view with its own
+        # generator state (round 3 built a full replica per worker)
+        self.net = self._build_net()
+        self.nets = [self.net] + [self.net.worker_view() for _ in range(self.S - 1)]
+        self.timers = [DecodeTimer(self.net.completion.decoder)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.S)]
         self.sinks = [MeshSink(self.device) for _ in range(self.S)]
         # scene pool: global scene id i -> seed 10 + (i mod pool), pool a multiple of the world size so
@@ -230,6 +233,14 @@ class HipBackend(object):
         for i in sharding.scene_ids_for_rank(self.pool, rank, world):
             pc = synthetic.synthetic_scene(seed=10 + i, n_points=args.points, n_raw=args.raw)
             self.scenes[i] = torch.from_numpy(pc).to(self.device)
+        torch.cuda.synchronize()
+        # one scene through worker 0 alone: every lazily built cache of the SHARED model (packed weight streams, folded
+        # BatchNorms, the round-0 query list) exists before several host threads use it concurrently
+        ctx = self.worker_begin(0)
+        try:
+            self.run_pass(0, [min(self.scenes)] * self.NB)
+        finally:
+            self.worker_end(0, ctx)
         torch.cuda.synchronize()
 
     def _build_net(self):
@@ -276,10 +287,10 @@ class HipBackend(object):
             sel = net.select_proposals(end_points, 'all', pc)
             gen = net.completion.generator
             # the previous scene's PCIe copy rides behind one decode launch (--blit-round; default the first, longest)
-            tm, blit_round = self.timers[w], self.args.blit_round
+            tm, blit_round = self.timers[0], self.args.blit_round
 
             def hook(r, depth):
-                tm.round = r
+                tm.local.round = r
                 if r == blit_round:
                     sink.start_pending()
             gen.round_hook = hook
@@ -293,7 +304,7 @@ class HipBackend(object):
         sink.push(v, f)
         if self.args.blit_round < 0:
             sink.start_pending()
-        if self.timers[w].enabled:
+        if self.timers[0].enabled:
             with DECODE_LOCK:
                 for r, n in enumerate(gen.stats.get('per_round', [])):
                     self.round_points[r] = self.round_points.get(r, 0) + int(n)
@@ -437,6 +448,8 @@ class HipBackend(object):
                                meshes[j].faces.cpu().numpy(), cpu_grid, thr, gen.padding)
             r["proposal"], r["cpu_queries"] = int(k), int(n_q)
             rows.append(r)
+            self.cpu_grids = getattr(self, "cpu_grids", []) + [cpu_grid]     # the CPU baseline's octree / MC legs reuse them
+        self.cpu_threshold = thr
         return {"what": "CPU path (oracle decoder + octree MISE + marching cubes) vs HIP path, scene 0, proposals %s"
                         % picks,
                 "min_iou": min(r["iou"] for r in rows), "flips": sum(r["flips"] for r in rows),
@@ -678,6 +691,60 @@ def grouping_roofline(device):
     return r
 
 
+VALU_PEAK_TFLOPS = 157.3      # fp32 vector peak, MI355X_MICROARCH.md (256 CUs x 4 SIMD x 64 lanes x 2 flop x 2.4 GHz)
+
+
+def pointop_rooflines(device, pc):
+    """SURVEY 8(d)'s per-op figures for the two point ops that are NOT HBM-bound, measured live (HIP events on the stream
+    the kernels are launched on) on the benchmark's own scene, at the call sites' shapes (pointnet2backbone.py:27-61,
+    skip_propagation.py:24-31):
+      furthest-point sampling (latency / on-chip bound): point-updates/s = N (M-1) / t and effective on-chip GB/s =
+        16 B N (M-1) / t -- what a kernel re-streaming the points every round (the reference's, sampling_gpu.cu:69-173)
+        would have to move; this kernel keeps them in registers and touches HBM for 12 N + 4 N + 4 M bytes only;
+      ball query (VALU / LDS bound): centre-point distance tests/s = M N / t (8 flop each).
+    `frac` is against the fp32 VALU peak at 8 flop per update / test; FPS runs on G <= 32 workgroups by design (the
+    exchange between workgroups every round is what bounds it), so its frac is a statement about latency, not ALUs."""
+    import torch
+    from rfdnet_amd.pointnet2_ops import _ext
+    xyz = pc[:, :3].contiguous()[None]
+    N = int(xyz.shape[1])
+
+    def timed(fn, it):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / it
+
+    peak_tests = VALU_PEAK_TFLOPS * 1e12 / 8.0
+    M = 2048
+    ms = timed(lambda: _ext.furthest_point_sampling(xyz, M), 5)
+    upd = N * (M - 1) / (ms * 1e-3)
+    fps = {"bound": "latency (inter-workgroup exchange per round); on-chip", "kernel": "fps_kernel, SA1 %d -> %d" % (N, M),
+           "avg_launch_ms": ms, "us_per_round": 1e3 * ms / (M - 1), "achieved": upd / 1e9, "unit": "G point-updates/s",
+           "peak": peak_tests / 1e9, "frac": upd / peak_tests, "effective_onchip_GBps": 16.0 * upd / 1e9,
+           "algorithmic_hbm_bytes_per_launch": 12 * N + 4 * N + 4 * M}
+    inds = _ext.furthest_point_sampling(xyz, M)
+    ctr = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    out = {}
+    for name, c, r, ns in (("sa1", ctr, 0.2, 64), ("skip_propagation", ctr[:, :256].contiguous(), 1.0, 1024)):
+        m = int(c.shape[1])
+        ms = timed(lambda: _ext.ball_query(c, xyz, r, ns), 20)
+        tests = m * N / (ms * 1e-3)
+        out[name] = {"shape": "%d centres x %d points, radius %.1f, nsample %d" % (m, N, r, ns), "avg_launch_ms": ms,
+                     "achieved": tests / 1e9, "frac": tests / peak_tests,
+                     "algorithmic_hbm_bytes_per_launch": 12 * N + 12 * m + 4 * m * ns}
+    bq = {"bound": "valu/lds", "kernel": "ball_query_kernel", "unit": "G distance tests/s", "peak": peak_tests / 1e9,
+          "achieved": out["sa1"]["achieved"], "frac": out["sa1"]["frac"], "avg_launch_ms": out["sa1"]["avg_launch_ms"],
+          "sa1": out["sa1"], "skip_propagation": out["skip_propagation"],
+          "note": "upper bound on the work: a workgroup stops scanning once all its centres hold nsample hits"}
+    return fps, bq
+
+
 def traffic_per_query():
     """HBM bytes per query point of the decoder from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this benchmark; counters cannot be read from
@@ -767,6 +834,8 @@ def main(argv=None):
         }
         if be.name in ("hip", "stress"):
             out["roofline_grouping"] = grouping_roofline(be.device)
+        if be.name == "hip":
+            out["roofline_fps"], out["roofline_ball_query"] = pointop_rooflines(be.device, be.scenes[min(be.scenes)])
         if single is not None:
             out["single_scene"] = {"scenes_in_flight": 1, "ms_per_scene": 1e3 * single,
                                    "scenes_per_s": 1.0 / single}
@@ -775,12 +844,14 @@ def main(argv=None):
             if stress:
                 out["cpu_baseline"] = cpu_baseline.run_decoder_only()
             else:
-                out["cpu_baseline"] = cpu_baseline.run(args.points, args.resolution0, args.upsampling_steps,
-                                                       int(dec_pts / per), int(gathered[0, F("n_meshes")] / per))
-                par = be.parity_sample()
+                par = be.parity_sample()         # first: its CPU value grids feed the baseline's octree / MC legs
                 if par is not None:
                     out["config"]["parity_iou"] = par["min_iou"]
                     out["parity"] = par
+                out["cpu_baseline"] = cpu_baseline.run(args.points, args.resolution0, args.upsampling_steps,
+                                                       int(dec_pts / per), int(gathered[0, F("n_meshes")] / per),
+                                                       scene_grids=getattr(be, "cpu_grids", None),
+                                                       threshold_logit=getattr(be, "cpu_threshold", 0.0))
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

@@ -125,11 +125,18 @@ int rfd_furthest_point_sampling_gather(int b, int n, int m,
 
 /* ---- diagnostics --------------------------------------------------------- */
 const char *rfd_last_error_string(void);
-/* Device-side status word of the persistent kernels (FPS exchange spin
- * limit).  Synchronises the device.  0 = OK. */
+/* Device-side status words of the persistent kernels (bit 0: FPS exchange spin
+ * limit; bit 1: occupancy decoder, bit 2: split-precision GEMMs -- an activation
+ * beyond the f16 range at the current scale).  One word per stream (64 slots per
+ * device; slot 0 is the null stream's and the overflow slot).  rfd_device_status
+ * synchronises the DEVICE and returns / clears the OR of all words.  0 = OK. */
 int rfd_device_status(void);
-/* The same word after waiting for `stream` only (other streams keep running). */
+/* The word of `stream` only, after waiting for that stream (other streams keep
+ * running and keep their own flags); cleared when reported. */
 int rfd_stream_status(void *stream);
+/* Give the status slot of `stream` back (callers that create a stream per scene);
+ * waits for the stream and returns its pending flags.  Not owning a slot is fine. */
+int rfd_release_stream(void *stream);
 /* "gfx950" etc. of the code object actually loaded. */
 const char *rfd_build_arch(void);
 

@@ -148,8 +148,11 @@ def _timed(fn, reps=1):
 
 
 def run(points=80000, resolution0=32, upsampling_steps=1, n_queries_per_scene=None, n_prop=256,
-        budget_s=20.0):
-    """-> the `cpu_baseline` object of bench.py's JSON line."""
+        budget_s=20.0, scene_grids=None, threshold_logit=0.0):
+    """-> the `cpu_baseline` object of bench.py's JSON line.
+    scene_grids: value grids (R+1)^3 of a few proposals of THE SCENE (the CPU path's own, computed by bench.py's parity
+    leg with the oracle decoder): the octree and marching-cubes legs then run on the scene's fields instead of an
+    analytic sphere -- the octree is replayed with the grid as its field (same queries, same subdivisions)."""
     import torch
     from oracle import oracle
     from rfdnet_amd import synthetic
@@ -284,10 +287,24 @@ def run(points=80000, resolution0=32, upsampling_steps=1, n_queries_per_scene=No
                          % (best, n_s, t_dec, n_s / t_dec, n_c, t_cdec, n_c / t_cdec, n_queries_per_scene))
 
     # ---- MISE octree + marching cubes: C oracle on a sample of proposals --------------------
-    n_m = 4
     grids = []
-    t0 = time.perf_counter()
-    if upsampling_steps > 0:
+    if scene_grids and upsampling_steps > 0:
+        n_m = len(scene_grids)
+        t0 = time.perf_counter()
+        for g in scene_grids:
+            g = np.asarray(g, np.float64)
+            m = oracle.MISE(resolution0, upsampling_steps, threshold_logit)
+            q = m.query()
+            while q.shape[0]:
+                m.update(q, g[q[:, 0], q[:, 1], q[:, 2]])
+                q = m.query()
+            grids.append(m.to_dense())
+        t['mise_octree'] = (time.perf_counter() - t0) / n_m * n_prop
+        sample['mise_octree'] = "%d of %d proposals of the scene (octree replayed on the CPU path's value grids)" % (n_m, n_prop)
+        thr_mc, what = threshold_logit, "the scene's value grids"
+    elif upsampling_steps > 0:
+        n_m = 4
+        t0 = time.perf_counter()
         for _ in range(n_m):
             m = oracle.MISE(resolution0, upsampling_steps, 0.0)
             q = m.query()
@@ -298,16 +315,21 @@ def run(points=80000, resolution0=32, upsampling_steps=1, n_queries_per_scene=No
             grids.append(m.to_dense())
         t['mise_octree'] = (time.perf_counter() - t0) / n_m * n_prop
         sample['mise_octree'] = "%d of %d proposals (analytic sphere field)" % (n_m, n_prop)
+        thr_mc, what = 0.0, "sphere grids"
     else:
+        n_m = 4
         n = resolution0
         idx = np.stack(np.meshgrid(*[np.linspace(-0.5, 0.5, n)] * 3, indexing="ij"), -1)
         grids = [0.35 - np.sqrt((idx ** 2).sum(-1))] * n_m
         t['mise_octree'] = 0.0
+        thr_mc, what = 0.0, "sphere grids"
     t0 = time.perf_counter()
+    faces = 0
     for g in grids:
-        oracle.extract_mesh(g, 0.0)
+        faces += len(oracle.extract_mesh(g, thr_mc)[1])
     t['marching_cubes'] = (time.perf_counter() - t0) / n_m * n_prop
-    sample['marching_cubes'] = "%d of %d proposals (%d^3 sphere grids)" % (n_m, n_prop, grids[0].shape[0])
+    sample['marching_cubes'] = "%d of %d proposals (%d^3, %s, %d faces per proposal)" % (
+        n_m, n_prop, grids[0].shape[0], what, faces // max(n_m, 1))
 
     total = sum(t.values())
     return {"value": 1.0 / total, "unit": "scenes/s", "cores": cores, "kind": "port",

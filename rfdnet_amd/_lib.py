@@ -63,7 +63,7 @@ _RESTYPES = {
     "rfd_device_status": C.c_int,
     "rfd_occ_packed_bytes": C.c_size_t,
 }
-_INT_FNS = {"rfd_stream_status": [_f]}
+_INT_FNS = {"rfd_stream_status": [_f], "rfd_release_stream": [_f]}
 _SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_chain_packed_bytes": [], "rfd_head_packed_bytes": []}
 
 _lib = None
@@ -153,6 +153,13 @@ def stream_status_bits():
     if st < 0:
         raise RfdHipError("rfd_stream_status failed")
     return st
+
+
+def release_stream(stream=None):
+    """Return the status slot of `stream` (default: the current one) to the pool; raises for flags still pending."""
+    import torch
+    st = lib().rfd_release_stream((stream or torch.cuda.current_stream()).cuda_stream)
+    return _raise_status(st)
 
 
 def device_status():

@@ -314,6 +314,9 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a) {
     float o = __builtin_fmaf(s_red[c], a.os3, s_b3[c]);
     if (a.relu3) o = o > 0.f ? o : 0.f;
     a.out[(size_t)prop * C3 + c] = o;
+    // the pooled feature is the next split-precision layer's INPUT (STN fc1, PointSeg's conv1 share): watch what is
+    // stored, like the row-owner GEMM's pool path does -- |o| 2^sa beyond f16 would saturate there silently
+    if (fabsf(o) * a.ascale >= 65504.f) atomicOr(a.status, 4u);
   }
   if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(a.status, 4u);
 }

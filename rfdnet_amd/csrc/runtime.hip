@@ -75,22 +75,40 @@ RFD_API int rfd_device_status(void) {
 }
 
 // The word of `stream` only: waits for that stream (several scenes may be in flight on other streams, each with
-// its own word, so a scene neither sees nor clears another scene's flags).  The shared word 0 (null stream, or
-// more streams than slots) is included read-only: it is cleared by rfd_device_status alone.
+// its own word, so a scene neither sees nor clears another scene's flags).  The shared word 0 belongs to the null
+// stream (and to streams beyond the 63 slots): it is reported to THEM and to rfd_device_status only -- round 3 folded
+// it read-only into every stream's answer, so one flag raised on the default stream made every scene in flight lower
+// its scales or fail until somebody cleared it.
 RFD_API int rfd_stream_status(void *stream) {
   RfdWorkspace *ws;
   if (rfd_get_workspace(&ws)) return -1;
   unsigned *word = rfd_status_word(ws, (hipStream_t)stream);
-  unsigned v[2] = {0, 0};
-  if (hipMemcpyAsync(&v[0], word, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
-    return -3;
-  if (word != ws->status &&
-      hipMemcpyAsync(&v[1], ws->status, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
-    return -3;
+  unsigned v = 0;
+  if (hipMemcpyAsync(&v, word, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -3;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -2;
-  // stream-ordered reset: only kernels of this stream write this word
-  if (v[0]) (void)hipMemsetAsync(word, 0, sizeof(unsigned), (hipStream_t)stream);
-  return (int)(v[0] | v[1]);
+  // stream-ordered reset: only kernels of this stream write this word (word 0: of the streams sharing it)
+  if (v) (void)hipMemsetAsync(word, 0, sizeof(unsigned), (hipStream_t)stream);
+  return (int)v;
+}
+
+// Give a stream's status slot back (a sweep that creates a stream per scene would otherwise run out of the 63 slots
+// and fall back to the shared word).  Waits for the stream, returns its pending flags (like rfd_stream_status) and
+// frees the slot; a stream that owns no slot is not an error.  The stream may be used again afterwards: it simply
+// claims a slot again at its next flag-raising launch.
+RFD_API int rfd_release_stream(void *stream) {
+  RfdWorkspace *ws;
+  if (rfd_get_workspace(&ws)) return -1;
+  if (!stream) return 0;
+  for (int i = 1; i < RFD_STATUS_SLOTS; ++i) {
+    if (ws->status_owner[i].load(std::memory_order_acquire) != stream) continue;
+    unsigned v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -2;
+    if (hipMemcpy(&v, ws->status + i, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    if (v && hipMemset(ws->status + i, 0, sizeof(unsigned)) != hipSuccess) return -3;
+    ws->status_owner[i].store(nullptr, std::memory_order_release);
+    return (int)v;
+  }
+  return 0;
 }
 
 RFD_API const char *rfd_build_arch(void) { return "gfx950"; }

@@ -56,6 +56,24 @@ class ISCNet(nn.Module):
         own.update({k: v for k, v in stripped.items() if k in own})
         self.load_state_dict(own)
 
+    def worker_view(self):
+        """A second handle on THIS network for another host thread / stream: every parameter, buffer, sub-module and
+        packed-weight cache is shared (read-only at inference); only the mesh generator -- the one object that keeps
+        per-call state (query statistics, the mesh buffers of the last call, the round hook) -- is the view's own.
+        Several scenes in flight per GPU then cost one set of weights, not one per scene."""
+        import copy
+        view = copy.copy(self)
+        view._modules = dict(self._modules)              # a dict of its own: re-pointing `completion` stays local
+        comp = copy.copy(self.completion)
+        comp.__dict__ = dict(self.completion.__dict__)
+        gen = copy.copy(self.completion.generator)
+        gen.__dict__ = dict(self.completion.generator.__dict__)
+        gen.model, gen.stats, gen.round_hook = comp, {}, None
+        gen.__dict__.pop('last_buffers', None)
+        comp.generator = gen
+        view._modules['completion'] = comp
+        return view
+
     # ---------------------------------------------------------------- stages ---
     def detect(self, point_clouds):
         """backbone -> voting (+L2 norm) -> proposal  (demo.py:206-221)."""
@@ -147,17 +165,20 @@ class ISCNet(nn.Module):
         for attempt in (0, 1):
             codes = self.object_codes(end_points, proposal_features, ids, pc)
             cls = self.cls_codes(end_points, ids)
+            # the stream's status word is read HERE, before the completion: a GEMM that overflowed has clipped the
+            # codes, and a decoder run on clipped codes could raise ITS range flag, lower the decoder's scale for good
+            # and hide the GEMM's flag behind status 6.  One stream wait per scene, behind the
+            # skip-propagation stage (the MISE loop that follows waits once per round anyway).
+            with torch.cuda.device(pc.device):
+                st = _lib.stream_status_bits()
+            if st & 4 and not st & ~4 and attempt == 0 and gemm.lower_scale():
+                continue                                   # the stage again at the fallback GEMM scale
+            _lib.raise_status(st)                          # FPS exchange time-out, or an overflow at the fallback scale
             if hook is not None:
                 hook(codes, cls)
-            try:
-                return self.complete(codes, cls, pc.device, return_grids=return_grids)
-            except _lib.RfdHipError as e:
-                if attempt == 0 and getattr(e, 'status', 0) & 4 and not getattr(e, 'status', 0) & ~4 \
-                        and gemm.lower_scale():
-                    continue
-                raise
+            return self.complete(codes, cls, pc.device, return_grids=return_grids)
 
-    def complete(self, codes, cls, device, return_grids=False, before_meshes=None):
+    def complete(self, codes, cls, device, return_grids=False):
         """Occupancy completion of the selected proposals + the status read that must follow it.
         FPS exchange time-outs and f16-range flags are reported through the stream's status word, not through
         return codes (the kernels are asynchronous): never hand back results without reading it (waits for THIS

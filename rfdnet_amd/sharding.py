@@ -74,13 +74,71 @@ def numa_cpus_for_gpu(index, sys_root="/sys"):
         return None
 
 
+def visible_device_index(local_rank, env=None):
+    """Physical (KFD order) index of the GPU that HIP calls device `local_rank`, honouring HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES remapping; None when a list is set that cannot be translated (UUIDs,
+    out of range): the caller then skips pinning rather than pin to another GPU's NUMA node."""
+    env = os.environ if env is None else env
+    idx = local_rank
+    # ROCR_VISIBLE_DEVICES filters what the runtime enumerates; HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is its alias,
+    # used only when the HIP variable is absent) indexes into that list: translate from the inside out
+    hip_var = "HIP_VISIBLE_DEVICES" if (env.get("HIP_VISIBLE_DEVICES") or "").strip() else "CUDA_VISIBLE_DEVICES"
+    for var in (hip_var, "ROCR_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is None or v.strip() == "":
+            continue
+        try:
+            ids = [int(x) for x in v.split(",") if x.strip() != ""]
+            idx = ids[idx]
+        except (ValueError, IndexError):
+            return None
+    return idx
+
+
+def pin_cpus_for_rank(local_rank, env=None, sys_root="/sys"):
+    """The CPUs rank `local_rank` may be pinned to: its GPU's NUMA node INTERSECTED with this process's allowed set
+    (docker --cpuset-cpus, the k8s static CPU manager: a cpulist outside it makes sched_setaffinity fail with EINVAL).
+    None = leave the affinity alone (no topology, remapping that cannot be translated, empty intersection)."""
+    phys = visible_device_index(local_rank, env)
+    if phys is None:
+        return None
+    cpus = numa_cpus_for_gpu(phys, sys_root)
+    if not cpus:
+        return None
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return None
+    cpus = sorted(set(cpus) & set(allowed))
+    return cpus or None
+
+
+def _pin(cpus):
+    """preexec_fn of a rank: never raise (an exception here becomes SubprocessError in the parent and aborts the launch)"""
+    try:
+        os.sched_setaffinity(0, cpus)
+    except (OSError, ValueError):
+        pass
+
+
+def _stop(procs):
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+
+
 def launch_local_ranks(script, argv, nproc, env=None, timeout=None):
     """One process per GPU of THIS node: re-executes `script argv` nproc times with the
     environment torch.distributed.run would set (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR=127.0.0.1 / MASTER_PORT), rank 0 inheriting stdout, each rank's host threads
-    pinned to the CPUs of its GPU's NUMA node when the topology says which (RFD_PIN_NUMA=0
-    disables it).  Returns the worst exit code; if a rank fails the others are terminated (no
-    orphan holding a GPU)."""
+    pinned to the CPUs of its GPU's NUMA node when the topology says which AND this process may
+    use them (pin_cpus_for_rank; RFD_PIN_NUMA=0 disables it).  Returns the worst exit code; if a
+    rank fails -- or cannot even be spawned -- the others are terminated (no orphan holding a GPU)."""
     base = dict(os.environ)
     base.update(env or {})
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(nproc),
@@ -92,10 +150,14 @@ def launch_local_ranks(script, argv, nproc, env=None, timeout=None):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         # host threads of rank r (its three scene workers, the pinned-memory copies) stay on the NUMA node of GPU r:
         # the mesh D2H copies and kernel launches do not cross the socket interconnect
-        cpus = numa_cpus_for_gpu(r) if pin else None
-        pre = (lambda c=cpus: os.sched_setaffinity(0, c)) if cpus else None
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
-                                      stdout=None if r == 0 else subprocess.DEVNULL, preexec_fn=pre))
+        cpus = pin_cpus_for_rank(r, base) if pin else None
+        pre = (lambda c=cpus: _pin(c)) if cpus else None
+        try:
+            procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
+                                          stdout=None if r == 0 else subprocess.DEVNULL, preexec_fn=pre))
+        except (OSError, subprocess.SubprocessError):
+            _stop(procs)               # a rank that cannot be spawned takes the ranks already started with it
+            raise
     import time
     t_end = None if timeout is None else time.time() + timeout
     rc = 0
@@ -108,13 +170,7 @@ def launch_local_ranks(script, argv, nproc, env=None, timeout=None):
                 if c != 0:
                     rc = rc or c
         if rc or (t_end is not None and time.time() > t_end):
-            for p in alive:
-                p.terminate()
-            for p in alive:
-                try:
-                    p.wait(10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
+            _stop(alive)
             return rc or 124
         time.sleep(0.05)
     return rc

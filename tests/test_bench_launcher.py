@@ -136,3 +136,67 @@ def test_numa_cpu_list_from_a_fake_topology(tmp_path):
     assert sharding.numa_cpus_for_gpu(0, str(root)) == [0, 1, 2, 3, 16, 17, 18, 19]
     assert sharding.numa_cpus_for_gpu(1, str(root)) == [4, 5, 6, 7]
     assert sharding.numa_cpus_for_gpu(2, str(root)) is None            # no such GPU: leave the affinity alone
+
+
+def test_pinning_respects_the_allowed_cpuset_and_device_remapping(tmp_path, monkeypatch):
+    """the NUMA cpulist is intersected with the launcher's own allowed set (a cpuset-confined
+    container: sched_setaffinity would fail with EINVAL), skipped when the intersection is empty, translated through
+    HIP_ / ROCR_VISIBLE_DEVICES and skipped when those cannot be translated; the preexec hook never raises."""
+    import os
+    from rfdnet_amd import sharding
+    root = tmp_path / "sys"
+    nodes = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    for i, (simd, loc) in enumerate([(0, 0), (256, 0x0500), (256, 0x2500)]):
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("simd_count %d\nlocation_id %d\ndomain 0\n" % (simd, loc))
+    for bdf, node in (("0000:05:00.0", "0"), ("0000:25:00.0", "1")):
+        d = root / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(node + "\n")
+    for n, cl in ((0, "0-3"), (1, "4-7")):
+        d = root / "devices" / "system" / "node" / ("node%d" % n)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+    sr = str(root)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {2, 3, 4, 5})
+    assert sharding.pin_cpus_for_rank(0, {}, sr) == [2, 3]                       # node 0 = 0-3, allowed 2-5
+    assert sharding.pin_cpus_for_rank(1, {}, sr) == [4, 5]
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {8, 9})
+    assert sharding.pin_cpus_for_rank(0, {}, sr) is None                         # empty intersection: leave it alone
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)))
+    assert sharding.pin_cpus_for_rank(0, {"HIP_VISIBLE_DEVICES": "1,0"}, sr) == [4, 5, 6, 7]    # device 0 = physical GPU 1
+    assert sharding.pin_cpus_for_rank(0, {"ROCR_VISIBLE_DEVICES": "1"}, sr) == [4, 5, 6, 7]
+    assert sharding.pin_cpus_for_rank(0, {"ROCR_VISIBLE_DEVICES": "1,0", "HIP_VISIBLE_DEVICES": "1"}, sr) == [0, 1, 2, 3]
+    assert sharding.pin_cpus_for_rank(0, {"CUDA_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0"}, sr) == [0, 1, 2, 3]
+    assert sharding.pin_cpus_for_rank(0, {"ROCR_VISIBLE_DEVICES": "GPU-deadbeef"}, sr) is None  # UUIDs: skip pinning
+    assert sharding.pin_cpus_for_rank(3, {"HIP_VISIBLE_DEVICES": "0"}, sr) is None               # out of range
+    assert sharding.visible_device_index(2, {}) == 2
+
+    def boom(pid, cpus):
+        raise OSError(22, "Invalid argument")
+    monkeypatch.setattr(os, "sched_setaffinity", boom)
+    sharding._pin([0, 1])                                                       # swallowed
+
+
+def test_a_rank_that_cannot_be_spawned_takes_the_started_ranks_with_it(tmp_path, monkeypatch):
+    """no orphan: if Popen fails for rank 1, rank 0 (already running) is terminated before the error propagates"""
+    import subprocess
+    import sys
+    import pytest
+    from rfdnet_amd import sharding
+    script = tmp_path / "sleeper.py"
+    script.write_text("import time\ntime.sleep(60)\n")
+    started = []
+    real = subprocess.Popen
+
+    def popen(*a, **k):
+        if started:
+            raise OSError("cannot spawn")
+        p = real(*a, **k)
+        started.append(p)
+        return p
+    monkeypatch.setattr(sharding.subprocess, "Popen", popen)
+    with pytest.raises(OSError):
+        sharding.launch_local_ranks(str(script), [], 2, env={"RFD_PIN_NUMA": "0"})
+    assert started and started[0].poll() is not None

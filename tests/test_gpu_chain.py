@@ -85,6 +85,26 @@ def test_chain_flags_activations_beyond_the_f16_range(hip):
         hip.device_status()
 
 
+def test_chain_pooled_output_is_range_checked_too(hip):
+    """The fused chain's POOLED output feeds a split-precision GEMM directly (_TNet.forward_rows: fc1 on the pooled
+    feature): like the GEMM's own pool-only path (tests/test_gpu_gemm.py::test_pool_only_launch_is_range_checked_too)
+    it must raise status bit 4 when |pooled| * 2^sa leaves the f16 range although every intermediate stayed inside
+    (ADVICE round 3)."""
+    from rfdnet_amd import chain
+    g = torch.Generator(device="cuda").manual_seed(2)
+    l1, l2, l3 = layers(g, 4)
+    x = torch.randn(1024, 4, device="cuda", generator=g)
+    chain.chain_pool(x, l1, l2, l3, 1024, True)
+    hip.device_status()                                  # clean
+    w3, b3 = l3
+    b3 = b3.clone()
+    b3[17] = 5000.0                                      # the last layer's bias alone pushes one pooled channel to ~5000
+    out = chain.chain_pool(x, l1, l2, (w3, b3), 1024, True)
+    assert float(out[0, 17]) > 4095.0                    # * 2^4 > 65504
+    with pytest.raises(hip.RfdHipError, match="split-precision GEMM"):
+        hip.device_status()
+
+
 @pytest.mark.parametrize("B,P,n_cls", [(3, 1024, 2), (2, 384, 2), (4, 1024, 1)])
 def test_head_matches_fp64_composition(hip, B, P, n_cls):
     """64 -> 512 (+ per-proposal bias, ReLU) -> 256 (ReLU) -> 128 (ReLU) -> n_cls scores (pointseg.py:131-154 folded)."""

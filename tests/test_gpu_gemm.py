@@ -195,6 +195,47 @@ def test_gemm_flags_activations_beyond_the_f16_range(hip):
         hip.device_status()                        # ... but the next split layer would saturate on it
 
 
+def test_default_stream_flags_stay_with_the_default_stream_and_slots_are_recycled(hip):
+    """(i) a flag raised on the NULL stream (shared word 0) must not show up in another stream's status
+    read -- round 3 folded word 0 into every stream's answer, so every scene in flight lowered its scales or failed
+    until somebody cleared it; (ii) a caller that creates a stream per scene gives the slot back with
+    rfd_release_stream: after far more streams than the 63 slots, two fresh streams still have words of their own."""
+    from rfdnet_amd import _lib, gemm
+    w = torch.randn(128, 32, device="cuda") * 0.1
+    bad = torch.zeros(128, 32, device="cuda")
+    bad[3, 5] = 5000.0
+    good = torch.zeros(128, 32, device="cuda")
+    torch.cuda.synchronize()
+    gemm.linear(bad, w)                                   # default stream -> word 0
+    s1 = torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        gemm.linear(good, w)
+        assert _lib.stream_status_bits() == 0             # not s1's business
+    assert _lib.stream_status_bits() == 4                 # the default stream's own read reports and clears it
+    assert _lib.stream_status_bits() == 0
+    _lib.release_stream(s1)
+    for i in range(150):                                  # 150 streams > 63 slots: each one releases its slot
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            gemm.linear(bad if i % 50 == 7 else good, w)
+            if i % 50 == 7:
+                with pytest.raises(hip.RfdHipError, match="split-precision GEMM"):
+                    _lib.release_stream()                 # pending flags are reported by the release, not lost
+            else:
+                _lib.release_stream()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sa):
+        gemm.linear(bad, w)
+    with torch.cuda.stream(sb):
+        gemm.linear(good, w)
+        assert _lib.stream_status_bits() == 0             # still isolated: sb did not fall back to the shared word
+    with torch.cuda.stream(sa):
+        assert _lib.stream_status_bits() == 4
+    _lib.release_stream(sa)
+    _lib.release_stream(sb)
+    hip.device_status()
+
+
 def test_pool_only_launch_is_range_checked_too(hip):
     """store=False launches feed the pooled maximum to the next split GEMM: the range watch covers them as well
     (round-2 advisory: `if (g.C && ...)` skipped them)."""
@@ -256,6 +297,10 @@ def test_scene_survives_a_gemm_range_flag(hip):
             with pytest.warns(RuntimeWarning, match="f16 range"):
                 grids = net.reconstruct(ep, pf, ids, pc, return_grids=True)
             assert gemm.SA == gemm.SA_FALLBACK
+            # the status word is read BEFORE the completion: the decoder never saw the clipped codes, so its own
+            # activation scale is untouched (round 3 ran it on them first and could lower it for good)
+            from rfdnet_amd import occ_fold
+            assert net.completion.decoder.ka == occ_fold.KA
             again = net.reconstruct(ep, pf, ids, pc, return_grids=True)     # no flag, no warning, same result
         assert torch.equal(grids, again) and torch.isfinite(grids).all()
         hip.device_status()

@@ -174,3 +174,27 @@ def test_the_reference_config_file_itself_loads():
         for k, v in DEFAULT_CONFIG[sect].items():
             assert cfg.config[sect][k] == v, (sect, k)       # our defaults ARE that file's values
     assert cfg.eval_overrides["cls_nms"] is True and cfg.eval_overrides["remove_empty_box"] is True
+
+
+def test_worker_view_shares_every_weight_but_not_the_generator_state():
+    """ISCNet.worker_view(): the handle bench.py gives each in-flight scene -- one set of parameters / buffers per GPU
+    (identical tensor objects, identical state_dict keys), a generator of its own (statistics, mesh buffers, round
+    hook), and re-pointing the view's `completion` leaves the base network untouched."""
+    from rfdnet_amd.iscnet.config import Config
+    from rfdnet_amd.iscnet.network import ISCNet
+    net = ISCNet(Config({'generation': {'resolution_0': 8, 'upsampling_steps': 1}}))
+    view = net.worker_view()
+    base_params = dict(net.named_parameters())
+    view_params = dict(view.named_parameters())
+    assert list(base_params) == list(view_params)
+    assert all(view_params[k] is base_params[k] for k in base_params)
+    assert all(a is b for a, b in zip(net.buffers(), view.buffers()))
+    assert list(net.state_dict()) == list(view.state_dict())
+    assert view.completion is not net.completion and view.completion.decoder is net.completion.decoder
+    g0, g1 = net.completion.generator, view.completion.generator
+    assert g1 is not g0 and g1.model is view.completion and g0.model is net.completion
+    assert (g1.resolution0, g1.upsampling_steps, g1.threshold) == (g0.resolution0, g0.upsampling_steps, g0.threshold)
+    g1.stats['n_queries'] = 5
+    g1.round_hook = lambda r, d: None
+    assert g0.stats == {} and g0.round_hook is None
+    assert net._modules['completion'] is net.completion and net.completion.generator is g0

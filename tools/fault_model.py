@@ -10,7 +10,9 @@ single-MFMA fault is tried against the measured error of the 16 points:
 The fault's effect on the 16 logits is propagated through the rest of the network; a candidate "explains" a bad group
 when the predicted error vector matches the measured one (relative residual << 1).
     python tools/fault_model.py gpurun_out/c34/dump          (all single-MFMA faults: none matches)
-    python tools/fault_model.py --fcp profiles/r03_fault_dump/outs.npz
+    python tools/fault_model.py --fcp profiles/r03_fault_dump/outs.npz     (a dump directory / npz produced by
+    RFD_DBG_DUMP=dir python tools/ab/prio_check.py; round 3's own dump is summarised in profiles/r03_fault_model.txt and
+    no longer tracked -- tests/golden/F_FAULT.npz keeps one process of it)
 --fcp: the hypothesis that DOES match (found through the exact zeros in some error vectors: the unaffected points are the
 ones whose ReLU is off for ONE input channel of block 0).  In the tile prologue H' = row0 + Wp p, one of the three terms
 of ONE channel is left out for the whole wave; every (channel, term) is tried, and for the best one the weight that WAS
