@@ -336,5 +336,7 @@ def test_mise_path_in_the_logit_bands_of_a_trained_checkpoint(hip, oracle, onet_
     # points of that coarse voxel are evaluated on one side and filled from the coarser level on the other (observed on
     # MI355X at codes x6.5: 1 flip with 2 points within 1e-4 of the threshold; none in the other bands)
     assert flips <= max(1, near)
-    assert off <= 27 * min(flips, near), (off, flips, near)
+    # (measured: 87 points for the one flip at codes x6.5 -- the 19 new points of the voxel plus what to_dense's
+    # forward fill along x, y, z copies from them)
+    assert off <= 125 * min(flips, near), (off, flips, near)
     assert queries == gen.stats['n_queries'] or flips
