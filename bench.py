@@ -79,10 +79,6 @@ def parse(argv=None):
     ap.add_argument("--blit-round", type=int, default=0,
                     help="MISE round whose decode launch the previous scene's device-to-host mesh copy is released "
                          "behind (0 = the first, longest launch; -1 = at once, when the meshes are complete)")
-    ap.add_argument("--cu-split", type=int, default=0,
-                    help="EXPERIMENT (profiles/r04_cu_mask.txt): run the detection stage (backbone, voting, proposals: "
-                         "furthest-point sampling and other latency-bound kernels) of every scene on a stream confined "
-                         "to this many CUs and everything else on a stream confined to the remaining ones")
     ap.add_argument("--mode", choices=["f16x3", "f16x1"], default="f16x3",
                     help="decoder arithmetic; f16x3 is the parity mode (1e-4 on logits)")
     args = ap.parse_args(argv)
@@ -225,18 +221,9 @@ class HipBackend(object):
         # ONE set of weights / packed weight streams per GPU; every in-flight worker gets a view with its own
         # generator state (round 3 built a full replica per worker)
         self.net = self._build_net()
-        if os.environ.get("RFD_BENCH_REPLICAS") == "1":          # A/B: round 3's one full replica per worker
-            self.nets = [self.net] + [self._build_net() for _ in range(self.S - 1)]
-            self.timers = [DecodeTimer(n.completion.decoder) for n in self.nets]
-        else:
-            self.nets = [self.net] + [self.net.worker_view() for _ in range(self.S - 1)]
-            self.timers = [DecodeTimer(self.net.completion.decoder)]
-        if args.cu_split > 0:
-            self.streams = [_lib.cu_masked_stream(0, args.cu_split, invert=True) for _ in range(self.S)]
-            self.light = [_lib.cu_masked_stream(0, args.cu_split) for _ in range(self.S)]
-        else:
-            self.streams = [torch.cuda.Stream(self.device) for _ in range(self.S)]
-            self.light = None
+        self.nets = [self.net] + [self.net.worker_view() for _ in range(self.S - 1)]
+        self.timers = [DecodeTimer(self.net.completion.decoder)]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.S)]
         self.sinks = [MeshSink(self.device) for _ in range(self.S)]
         # scene pool: global scene id i -> seed 10 + (i mod pool), pool a multiple of the world size so
         # that a rank always meets the same resident scenes (its residue class)
@@ -294,32 +281,13 @@ class HipBackend(object):
         if ev:
             ev[0].record()
         with torch.no_grad():
-            if self.light is not None:
-                # --cu-split: the detection stage on the small CU partition, handed over to the scene's main stream (the
-                # big partition) with one event; its tensors are marked as used by the main stream for the allocator
-                main, light = torch.cuda.current_stream(), self.light[w]
-                start = torch.cuda.Event()
-                start.record()
-                with torch.cuda.stream(light):
-                    light.wait_event(start)
-                    end_points, proposal_features = net.detect(pc)
-                    sel = net.select_proposals(end_points, 'all', pc)
-                    done = torch.cuda.Event()
-                    done.record()
-                    self._lib.stream_status()            # the FPS time-out flag lives in the light stream's word
-                main.wait_event(done)
-                for t_ in list(end_points.values()) + [proposal_features, sel]:
-                    if torch.is_tensor(t_):
-                        t_.record_stream(main)
-                pc.record_stream(light)
-            else:
-                end_points, proposal_features = net.detect(pc)
-                sel = net.select_proposals(end_points, 'all', pc)
+            end_points, proposal_features = net.detect(pc)
+            sel = net.select_proposals(end_points, 'all', pc)
             if ev:
                 ev[1].record()
             gen = net.completion.generator
             # the previous scene's PCIe copy rides behind one decode launch (--blit-round; default the first, longest)
-            tm, blit_round = self.timers[w % len(self.timers)], self.args.blit_round
+            tm, blit_round = self.timers[0], self.args.blit_round
 
             def hook(r, depth):
                 tm.local.round = r

@@ -137,11 +137,6 @@ int rfd_stream_status(void *stream);
 /* Give the status slot of `stream` back (callers that create a stream per scene);
  * waits for the stream and returns its pending flags.  Not owning a slot is fine. */
 int rfd_release_stream(void *stream);
-/* A HIP stream confined to compute units [first_cu, first_cu + n_cus) -- or, invert != 0, to
- * all others -- of the current device (hipExtStreamCreateWithCUMask).  Experiment plumbing of
- * bench.py --cu-split; the caller destroys it with rfd_stream_destroy. */
-int rfd_stream_create_cu_mask(int first_cu, int n_cus, int invert, void **stream);
-int rfd_stream_destroy(void *stream);
 /* "gfx950" etc. of the code object actually loaded. */
 const char *rfd_build_arch(void);
 

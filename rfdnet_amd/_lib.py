@@ -37,8 +37,6 @@ SIGNATURES = {
     "rfd_occ_decode_w8": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],
     "rfd_occ_decode_scatter_w8": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _f, _f, C.c_longlong, _i, _f],
     "rfd_occ_chunk_range": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
-    "rfd_stream_create_cu_mask": [_i, _i, _i, C.POINTER(C.c_void_p)],
-    "rfd_stream_destroy": [_f],
     "rfd_make_grid_points": [_i, _fl, _fl, _fl, _f, _i, _f],
     "rfd_mise_init": [_i, _i, _i, _f, _f, _f],
     "rfd_mise_count": [_i, _i, _i, _f, _f, _f],
@@ -155,14 +153,6 @@ def stream_status_bits():
     if st < 0:
         raise RfdHipError("rfd_stream_status failed")
     return st
-
-
-def cu_masked_stream(first_cu, n_cus, invert=False):
-    """torch stream over a HIP stream confined to CUs [first_cu, first_cu + n_cus) (or to all others)."""
-    import torch
-    h = C.c_void_p()
-    check(lib().rfd_stream_create_cu_mask(first_cu, n_cus, int(invert), C.byref(h)), "rfd_stream_create_cu_mask")
-    return torch.cuda.ExternalStream(h.value)
 
 
 def release_stream(stream=None):

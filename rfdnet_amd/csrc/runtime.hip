@@ -111,36 +111,4 @@ RFD_API int rfd_release_stream(void *stream) {
   return 0;
 }
 
-// A stream confined to a subset of the compute units (hipExtStreamCreateWithCUMask): CUs [first_cu, first_cu + n_cus)
-// of the device's num_cu, or -- invert != 0 -- every CU EXCEPT those.  Used by the benchmark's --cu-split experiment
-// (latency-bound detection stage on a few CUs beside the persistent decoder on the rest; profiles/r04_cu_mask.txt);
-// not used by the default path.  The caller owns the stream (rfd_stream_destroy).
-RFD_API int rfd_stream_create_cu_mask(int first_cu, int n_cus, int invert, void **stream) {
-  RfdWorkspace *ws;
-  int rc = rfd_get_workspace(&ws);
-  if (rc) return rc;
-  const int ncu = ws->num_cu > 0 ? ws->num_cu : 256;
-  if (!stream || first_cu < 0 || n_cus <= 0 || first_cu + n_cus > ncu || (invert && n_cus >= ncu)) {
-    rfd_set_error("rfd_stream_create_cu_mask: range", hipErrorInvalidValue);
-    return (int)hipErrorInvalidValue;
-  }
-  const int words = (ncu + 31) / 32;
-  uint32_t mask[32] = {0};
-  for (int c = 0; c < ncu; ++c) {
-    const bool in = c >= first_cu && c < first_cu + n_cus;
-    if (in != (invert != 0)) mask[c >> 5] |= 1u << (c & 31);
-  }
-  hipStream_t s;
-  RFD_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
-  *stream = (void *)s;
-  return 0;
-}
-
-RFD_API int rfd_stream_destroy(void *stream) {
-  if (!stream) return 0;
-  (void)rfd_release_stream(stream);
-  RFD_CHECK(hipStreamDestroy((hipStream_t)stream));
-  return 0;
-}
-
 RFD_API const char *rfd_build_arch(void) { return "gfx950"; }

@@ -16,8 +16,6 @@ kernels here, see predictions.py).  'all' keeps every one of the num_target
 proposals (BASELINE configs 1-4 are quoted on "256 proposals"); 'objectness'
 applies the probability threshold only.
 """
-import os
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -171,10 +169,8 @@ class ISCNet(nn.Module):
             # codes, and a decoder run on clipped codes could raise ITS range flag, lower the decoder's scale for good
             # and hide the GEMM's flag behind status 6.  One stream wait per scene, behind the
             # skip-propagation stage (the MISE loop that follows waits once per round anyway).
-            st = 0
-            if os.environ.get("RFD_STATUS_LATE") != "1":       # (A/B switch of the benchmark: skip this early read)
-                with torch.cuda.device(pc.device):
-                    st = _lib.stream_status_bits()
+            with torch.cuda.device(pc.device):
+                st = _lib.stream_status_bits()
             if st & 4 and not st & ~4 and attempt == 0 and gemm.lower_scale():
                 continue                                   # the stage again at the fallback GEMM scale
             _lib.raise_status(st)                          # FPS exchange time-out, or an overflow at the fallback scale
