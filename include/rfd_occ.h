@@ -196,6 +196,10 @@ int rfd_occ_decode_scatter_w8(int n_tiles, const float *pts, const int *tile_pro
  * each batch half of what is left, single tiles at the end; *begin == *end == n_tiles past the last chunk.  Host-side
  * view of the schedule for tests and tools; the kernel evaluates the same function. */
 int rfd_occ_chunk_range(int k, int n_tiles, int n_workgroups, int *begin, int *end);
+/* The same schedule with no chunk larger than max_chunk tiles (max_chunk = 0: uncapped) -- the shape of the
+ * one-workgroup-per-chunk launch (RFD_DECODER_CHUNK); *n_chunks (optional) = number of non-empty chunks = its grid. */
+int rfd_occ_chunk_range_capped(int k, int n_tiles, int n_workgroups, int max_chunk, int *begin, int *end,
+                               int *n_chunks);
 
 /* ---- fp32-class GEMM on the f16 matrix cores (csrc/gemm_f16x3.hip) -----------------
  * C[M,N] = act(A)[M,K] . W[N,K]^T (+ bias[N]) (+ gbias[m / rows_per_group][N]) (+ R[M,N]),

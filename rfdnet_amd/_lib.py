@@ -37,6 +37,7 @@ SIGNATURES = {
     "rfd_occ_decode_w8": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _i, _f],
     "rfd_occ_decode_scatter_w8": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _f, _f, C.c_longlong, _i, _f],
     "rfd_occ_chunk_range": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "rfd_occ_chunk_range_capped": [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "rfd_make_grid_points": [_i, _fl, _fl, _fl, _f, _i, _f],
     "rfd_mise_init": [_i, _i, _i, _f, _f, _f],
     "rfd_mise_count": [_i, _i, _i, _f, _f, _f],

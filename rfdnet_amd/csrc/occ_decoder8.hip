@@ -69,6 +69,11 @@
 #ifndef DEC8_THIN
 #define DEC8_THIN 0
 #endif
+// default launch shape of the eight-wave decoder: 0 = persistent grid + run-time claiming; c > 0 = one workgroup per
+// chunk of at most c tiles (RFD_DECODER_CHUNK overrides it per process)
+#ifndef RFD_OCC_DEFAULT_CHUNK
+#define RFD_OCC_DEFAULT_CHUNK 0
+#endif
 #ifndef DEC8_BF16C
 #define DEC8_BF16C 0
 #endif
@@ -113,18 +118,22 @@ constexpr int SMEM_BYTES = SMEM_TAB_BYTES + 4 * HALF_BYTES;
 // Counter pair {next chunk, workgroups done} comes from a pool in the workspace (slot = launch sequence number mod
 // RFD_CLAIM_SLOTS, so concurrent launches on different streams never share one) and is reset by the last workgroup
 // to leave: no memset launch in front of the kernel.
-__host__ __device__ __forceinline__ void chunk_range(int k, int n_tiles, int W, int &b, int &e) {
+// cap > 0: no chunk larger than `cap` tiles (the one-chunk-per-workgroup launch below: a workgroup must not hold its CU
+// for longer than ~cap x 0.1 ms).
+__host__ __device__ __forceinline__ void chunk_range(int k, int n_tiles, int W, int &b, int &e, int cap = 0) {
   int base = 0, rem = n_tiles;
   const int batch = k / W, i = k - batch * W;
   for (int q = 0; q < batch && rem > 0; ++q) {
     int s = (rem + 2 * W - 1) / (2 * W);
     s = s < 1 ? 1 : s;
+    s = cap > 0 && s > cap ? cap : s;
     const int take = s * W < rem ? s * W : rem;
     base += take;
     rem -= take;
   }
   int s = (rem + 2 * W - 1) / (2 * W);
   s = s < 1 ? 1 : s;
+  s = cap > 0 && s > cap ? cap : s;
   const long long lb = (long long)i * s;
   if (lb >= rem) {
     b = e = n_tiles;
@@ -397,6 +406,12 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   int t_begin, t_end;
   if (claim) {
     next_chunk(t_begin, t_end);
+  } else if (tiles_per_wg < 0) {
+    // one chunk per workgroup (NOT persistent): chunk = blockIdx.x of the capped schedule (W = -tiles_per_wg >> 8,
+    // cap = -tiles_per_wg & 255).  The hardware hands the workgroups out as CUs fall free -- the same run-time balance as
+    // claiming -- and BETWEEN two of them a CU is up for grabs: another stream's kernel (the next scene's furthest-point
+    // sampling, a MISE pass, a GEMM) gets in within one chunk (~1-2 ms) instead of waiting for the whole launch.
+    chunk_range((int)blockIdx.x, n_tiles, (-tiles_per_wg) >> 8, t_begin, t_end, (-tiles_per_wg) & 255);
   } else {
     t_begin = blockIdx.x * tiles_per_wg;
     t_end = (t_begin + tiles_per_wg) < n_tiles ? (t_begin + tiles_per_wg) : n_tiles;
@@ -727,11 +742,35 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
 
 }  // namespace
 
+// number of non-empty chunks of the capped schedule
+static int chunk_count(int n_tiles, int W, int cap) {
+  int rem = n_tiles, n = 0;
+  while (rem > 0) {
+    int s = (rem + 2 * W - 1) / (2 * W);
+    s = s < 1 ? 1 : s;
+    s = cap > 0 && s > cap ? cap : s;
+    const int take = s * W < rem ? s * W : rem;
+    n += (take + s - 1) / s;
+    rem -= take;
+  }
+  return n;
+}
+
 // The chunk schedule of the eight-wave decoder as the host sees it (tests/test_chunk_schedule.py: the chunks of a launch
 // partition [0, n_tiles) for every grid size).
 RFD_API int rfd_occ_chunk_range(int k, int n_tiles, int n_workgroups, int *begin, int *end) {
   if (k < 0 || n_tiles < 0 || n_workgroups <= 0 || !begin || !end) return (int)hipErrorInvalidValue;
   chunk_range(k, n_tiles, n_workgroups, *begin, *end);
+  return 0;
+}
+
+// The same with chunks capped at max_chunk tiles (the one-chunk-per-workgroup launch); returns the number of chunks
+// through *n_chunks when it is not NULL.
+RFD_API int rfd_occ_chunk_range_capped(int k, int n_tiles, int n_workgroups, int max_chunk, int *begin, int *end,
+                                       int *n_chunks) {
+  if (k < 0 || n_tiles < 0 || n_workgroups <= 0 || max_chunk < 0 || !begin || !end) return (int)hipErrorInvalidValue;
+  chunk_range(k, n_tiles, n_workgroups, *begin, *end, max_chunk);
+  if (n_chunks) *n_chunks = chunk_count(n_tiles, n_workgroups, max_chunk);
   return 0;
 }
 
@@ -763,9 +802,19 @@ static int decode_w8(int n_tiles, const float *pts, const int *tile_prop, const 
   // (read per launch: tests flip it inside one process)
   const char *static_env = getenv("RFD_DECODER_STATIC");
   const bool static_part = static_env && atoi(static_env) != 0;
-  const int tiles_per_wg = ceil_div(n_tiles, ncu);
-  const int grid = static_part ? ceil_div(n_tiles, tiles_per_wg) : (n_tiles < ncu ? n_tiles : ncu);
+  // RFD_DECODER_CHUNK=c (1..255): NOT persistent -- one workgroup per chunk of at most c tiles (see the kernel);
+  // 0 / unset: the persistent grid with run-time claiming
+  const char *chunk_env = getenv("RFD_DECODER_CHUNK");
+  int cap = chunk_env ? atoi(chunk_env) : RFD_OCC_DEFAULT_CHUNK;
+  cap = cap < 0 ? 0 : cap > 255 ? 255 : cap;
+  int tiles_per_wg = ceil_div(n_tiles, ncu);
+  int grid = static_part ? ceil_div(n_tiles, tiles_per_wg) : (n_tiles < ncu ? n_tiles : ncu);
   unsigned *claim = static_part ? nullptr : rfd_claim_pair(ws);
+  if (!static_part && cap > 0) {
+    claim = nullptr;
+    tiles_per_wg = -((ncu << 8) | cap);
+    grid = chunk_count(n_tiles, ncu, cap);
+  }
   if (mode == RFD_OCC_MODE_F16X3) {
     hipLaunchKernelGGL(occ_decode8_kernel<3>, dim3(grid), dim3(512), 0, s, n_tiles, pts, tile_prop, tile_src,
                        (const half8 *)packed, fc_p_w, table, fc_out_w, fc_out_b, logits, rfd_status_word(ws, s), tiles_per_wg,

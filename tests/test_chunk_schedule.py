@@ -54,3 +54,31 @@ def test_bad_arguments_are_refused():
     b, e = C.c_int(), C.c_int()
     assert lib.rfd_occ_chunk_range(-1, 10, 4, C.byref(b), C.byref(e)) != 0
     assert lib.rfd_occ_chunk_range(0, 10, 0, C.byref(b), C.byref(e)) != 0
+
+
+@pytest.mark.parametrize("n,W,cap", [(1, 256, 16), (300, 256, 16), (11327, 256, 16), (71936, 256, 16), (71936, 256, 8),
+                                     (71936, 244, 32), (524288, 256, 16), (1000, 3, 5), (5000, 256, 255)])
+def test_capped_chunks_partition_the_launch_and_never_exceed_the_cap(n, W, cap):
+    """the one-workgroup-per-chunk launch (RFD_DECODER_CHUNK): same schedule, no chunk above `cap` tiles, and the
+    reported chunk count is exactly the number of non-empty chunks (= the kernel's grid)"""
+    from rfdnet_amd import _lib
+    lib = _lib.lib()
+    b, e, cnt = C.c_int(), C.c_int(), C.c_int()
+    assert lib.rfd_occ_chunk_range_capped(0, n, W, cap, C.byref(b), C.byref(e), C.byref(cnt)) == 0
+    total = cnt.value
+    pos, sizes = 0, []
+    for k in range(total):
+        lib.rfd_occ_chunk_range_capped(k, n, W, cap, C.byref(b), C.byref(e), None)
+        assert b.value == pos and b.value < e.value <= n, (k, b.value, e.value, pos)
+        sizes.append(e.value - b.value)
+        pos = e.value
+    assert pos == n and max(sizes) <= cap
+    lib.rfd_occ_chunk_range_capped(total, n, W, cap, C.byref(b), C.byref(e), None)
+    assert b.value == e.value == n
+    if n >= 4 * W * cap:
+        assert sizes[0] == cap and sizes[-1] == 1
+    # cap = 0 is the uncapped schedule
+    lib.rfd_occ_chunk_range_capped(3, n, W, 0, C.byref(b), C.byref(e), None)
+    b2, e2 = C.c_int(), C.c_int()
+    lib.rfd_occ_chunk_range(3, n, W, C.byref(b2), C.byref(e2))
+    assert (b.value, e.value) == (b2.value, e2.value)

@@ -211,6 +211,12 @@ def test_claimed_chunks_and_static_partition_give_identical_logits(hip):
             finally:
                 del os.environ["RFD_DECODER_STATIC"]
             runs = [dec.decode_tiles(pts, tile_prop, table, fcp) for _ in range(3)]
+            for cap in ("0", "1", "5", "16", "255"):       # persistent + claiming / one workgroup per chunk of <= cap tiles
+                os.environ["RFD_DECODER_CHUNK"] = cap
+                try:
+                    runs.append(dec.decode_tiles(pts, tile_prop, table, fcp))
+                finally:
+                    del os.environ["RFD_DECODER_CHUNK"]
         hip.device_status()
         for r in runs:
             assert torch.equal(r[keep], ref[keep])
