@@ -68,6 +68,9 @@ def parse(argv=None):
                     help="write per-scene statistics (stage ms from HIP events on the scene's stream, query points, "
                          "vertices, triangles, failed) of the timed region as JSON to this path (rank r > 0: "
                          "<path>.rank<r>); the reference prints per-scene time only (demo.py:408-411)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the per-op roofline measurements after the timed region (grouping, furthest-point sampling, "
+                         "ball query): profiling runs that want the scene's own kernels only")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the one-scene-at-a-time pass after the timed region")
     ap.add_argument("--in-flight", type=int, default=3,
@@ -234,14 +237,9 @@ class HipBackend(object):
             pc = synthetic.synthetic_scene(seed=10 + i, n_points=args.points, n_raw=args.raw)
             self.scenes[i] = torch.from_numpy(pc).to(self.device)
         torch.cuda.synchronize()
-        # one scene through worker 0 alone: every lazily built cache of the SHARED model (packed weight streams, folded
-        # BatchNorms, the round-0 query list) exists before several host threads use it concurrently
-        ctx = self.worker_begin(0)
-        try:
-            self.run_pass(0, [min(self.scenes)] * self.NB)
-        finally:
-            self.worker_end(0, ctx)
-        torch.cuda.synchronize()
+        # (the lazily built caches of the SHARED model -- packed weight streams, folded BatchNorms -- are built under
+        # _lib.BUILD_LOCK and published before they are stored, so the workers may start together.  A priming scene run
+        # from THIS thread was tried instead and cost 8 % scenes/s for the rest of the process: profiles/r04_numa_prime.txt)
 
     def _build_net(self):
         from rfdnet_amd import synthetic
@@ -769,6 +767,13 @@ def main(argv=None):
                  "and let bench.py spawn its own ranks)" % (args.gpus, world, args.gpus))
     cls = StubBackend if os.environ.get("RFD_BENCH_STUB") == "1" else \
         StressBackend if args.config == "stress" else HipBackend
+    if cls is not StubBackend and os.environ.get("RFD_PIN_NUMA", "1") != "0" and not os.environ.get("RFD_BENCH_ONE_DEVICE"):
+        # host threads, pinned mesh buffers (first touch) and the HIP runtime's helper threads on the CPUs of THIS GPU's
+        # NUMA node -- also with one rank, and when torch.distributed.run (not sharding.launch_local_ranks) started the
+        # ranks.  +1-2 % scenes/s on a two-socket box (profiles/r04_numa_prime.txt).
+        cpus = sharding.pin_cpus_for_rank(local_rank)
+        if cpus:
+            sharding._pin(cpus)
     be = cls(args, rank, local_rank, world)
     dist = None
     # RFD_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL barrier /
@@ -832,9 +837,9 @@ def main(argv=None):
                          "note": "algorithmic FLOPs (1 312 768 per query point) over HIP-event time of the decoder "
                                  "launches inside the timed region; f16x3 issues 3x that on the MFMA pipe"},
         }
-        if be.name in ("hip", "stress"):
+        if be.name in ("hip", "stress") and not args.no_extras:
             out["roofline_grouping"] = grouping_roofline(be.device)
-        if be.name == "hip":
+        if be.name == "hip" and not args.no_extras:
             out["roofline_fps"], out["roofline_ball_query"] = pointop_rooflines(be.device, be.scenes[min(be.scenes)])
         if single is not None:
             out["single_scene"] = {"scenes_in_flight": 1, "ms_per_scene": 1e3 * single,

@@ -134,6 +134,9 @@ int rfd_device_status(void);
 /* The word of `stream` only, after waiting for that stream (other streams keep
  * running and keep their own flags); cleared when reported. */
 int rfd_stream_status(void *stream);
+/* Asynchronous snapshot: the word is copied to *host_word (PINNED host memory; valid after the
+ * caller's next synchronisation of `stream`) and reset, in stream order.  Nothing waits. */
+int rfd_stream_status_snapshot(void *stream, unsigned *host_word);
 /* Give the status slot of `stream` back (callers that create a stream per scene);
  * waits for the stream and returns its pending flags.  Not owning a slot is fine. */
 int rfd_release_stream(void *stream);

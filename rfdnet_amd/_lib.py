@@ -64,10 +64,24 @@ _RESTYPES = {
     "rfd_device_status": C.c_int,
     "rfd_occ_packed_bytes": C.c_size_t,
 }
-_INT_FNS = {"rfd_stream_status": [_f], "rfd_release_stream": [_f]}
+_INT_FNS = {"rfd_stream_status": [_f], "rfd_release_stream": [_f], "rfd_stream_status_snapshot": [_f, _f]}
 _SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_chain_packed_bytes": [], "rfd_head_packed_bytes": []}
 
 _lib = None
+
+# Lazily built, cached artefacts (packed weight streams, folded BatchNorms, stacked weights) are shared by every host
+# thread that runs the same network (bench.py: several scenes in flight on one model).  A miss is built under this lock,
+# and published -- the building stream drained -- before it is stored, so a thread that finds the entry may use it on
+# ITS stream at once.
+import threading as _threading
+BUILD_LOCK = _threading.RLock()
+
+
+def publish(device=None):
+    """drain the current stream of `device`: what was just built on it is complete for every other stream"""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.current_stream(device).synchronize()
 
 
 class RfdHipError(RuntimeError):
@@ -154,6 +168,29 @@ def stream_status_bits():
     if st < 0:
         raise RfdHipError("rfd_stream_status failed")
     return st
+
+
+_snap_bufs = {}
+
+
+class StatusSnapshot(object):
+    """the current stream's status word as it stood when the snapshot was taken; read() after the stream has been
+    synchronised (by the caller's next status read, a `.cpu()`, ...)"""
+
+    def __init__(self):
+        import torch
+        s = torch.cuda.current_stream()
+        key = (torch.cuda.current_device(), s.cuda_stream, _threading.get_ident())
+        buf = _snap_bufs.get(key)
+        if buf is None:
+            buf = _snap_bufs[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.buf = buf
+        st = lib().rfd_stream_status_snapshot(s.cuda_stream, buf.data_ptr())
+        if st < 0:
+            raise RfdHipError("rfd_stream_status_snapshot failed")
+
+    def read(self):
+        return int(self.buf[0]) & 0xffffffff
 
 
 def release_stream(stream=None):

@@ -22,11 +22,27 @@ def usable(x, P, d_in):
     return ok and d_in == 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
 
 
+def _cached(key, build):
+    """shared by every host thread running the same network: a miss is built under the library's build lock and published
+    (building stream drained) before it is stored (_lib.BUILD_LOCK)"""
+    hit = _cache.get(key)
+    if hit is None:
+        with _lib.BUILD_LOCK:
+            hit = _cache.get(key)
+            if hit is None:
+                hit = build()
+                if len(_cache) > 64:
+                    _cache.clear()
+                _lib.publish(hit[0].device)
+                _cache[key] = hit
+    return hit
+
+
 def _packed(mode, layers):
     (W1, _), (W2, _), (W3, _) = layers
     key = tuple((None if w is None else (w.data_ptr(), w._version, tuple(w.shape))) for w in (W1, W2, W3)) + (mode,)
-    hit = _cache.get(key)
-    if hit is None:
+
+    def build():
         assert tuple(W2.shape) == (128, 64) and tuple(W3.shape) == (1024, 128), (W2.shape, W3.shape)
         sw1 = occ_fold.choose_kw([W1]) if mode == 2 else 0
         sw2, sw3 = occ_fold.choose_kw([W2]), occ_fold.choose_kw([W3])
@@ -38,11 +54,8 @@ def _packed(mode, layers):
                                            w3c.data_ptr(), sw1, sw2, sw3, buf.data_ptr(), _lib.current_stream())
         _lib.check(rc, "rfd_chain_pack")
         torch.cuda.current_stream(W2.device).synchronize()          # w?c may be temporaries
-        hit = (buf, sw1, sw2, sw3, (W1, W2, W3))                     # keep the keyed tensors alive
-        if len(_cache) > 64:
-            _cache.clear()
-        _cache[key] = hit
-    return hit
+        return (buf, sw1, sw2, sw3, (W1, W2, W3))                    # keep the keyed tensors alive
+    return _cached(key, build)
 
 
 def chain_pool(x, layer1, layer2, layer3, P, relu3):
@@ -77,8 +90,8 @@ def head_usable(x, P, n_cls):
 
 def _head_packed(Wa, Wb, Wc):
     key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in (Wa, Wb, Wc)) + ("head",)
-    hit = _cache.get(key)
-    if hit is None:
+
+    def build():
         assert tuple(Wa.shape) == (512, 64) and tuple(Wb.shape) == (256, 512) and tuple(Wc.shape) == (128, 256)
         swa, swb, swc = (occ_fold.choose_kw([w]) for w in (Wa, Wb, Wc))
         buf = torch.empty(_lib.lib().rfd_head_packed_bytes(), dtype=torch.uint8, device=Wa.device)
@@ -88,11 +101,8 @@ def _head_packed(Wa, Wb, Wc):
                                           _lib.current_stream())
         _lib.check(rc, "rfd_head_pack")
         torch.cuda.current_stream(Wa.device).synchronize()
-        hit = (buf, swa, swb, swc, (Wa, Wb, Wc))
-        if len(_cache) > 64:
-            _cache.clear()
-        _cache[key] = hit
-    return hit
+        return (buf, swa, swb, swc, (Wa, Wb, Wc))
+    return _cached(key, build)
 
 
 def head_scores(x, P, Wa, gbias, layer_b, layer_c, Wd, bd):

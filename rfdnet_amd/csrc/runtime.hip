@@ -91,6 +91,20 @@ RFD_API int rfd_stream_status(void *stream) {
   return (int)v;
 }
 
+// Asynchronous form for callers that must not wait here: the word of `stream` is copied to *host_word (pinned host
+// memory, valid once the stream has been synchronised by whatever the caller waits for next) and reset, both in stream
+// order -- flags raised by later launches are then distinguishable from the ones raised so far.
+RFD_API int rfd_stream_status_snapshot(void *stream, unsigned *host_word) {
+  RfdWorkspace *ws;
+  if (rfd_get_workspace(&ws)) return -1;
+  if (!host_word) return -3;
+  unsigned *word = rfd_status_word(ws, (hipStream_t)stream);
+  if (hipMemcpyAsync(host_word, word, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+    return -3;
+  if (hipMemsetAsync(word, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return -3;
+  return 0;
+}
+
 // Give a stream's status slot back (a sweep that creates a stream per scene would otherwise run out of the 63 slots
 // and fall back to the shared word).  Waits for the stream, returns its pending flags (like rfd_stream_status) and
 // frees the slot; a stream that owns no slot is not an error.  The stream may be used again afterwards: it simply

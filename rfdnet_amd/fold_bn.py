@@ -22,6 +22,16 @@ def folded(layer, bn=None):
     hit = layer.__dict__.get('_folded')
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
+    from . import _lib
+    with _lib.BUILD_LOCK:                    # shared across host threads: built once, published before it is stored
+        hit = layer.__dict__.get('_folded')
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        return _fold_now(layer, bn, w, key)
+
+
+def _fold_now(layer, bn, w, key):
+    from . import _lib
     W = w.detach().reshape(w.shape[0], -1)
     b = layer.bias.detach() if layer.bias is not None else torch.zeros(W.shape[0], device=W.device, dtype=W.dtype)
     if bn is not None:
@@ -32,6 +42,8 @@ def folded(layer, bn=None):
         W = W * s[:, None]
         b = (b - bn.running_mean) * s + beta
     W, b = W.contiguous(), b.contiguous()
+    if W.is_cuda:
+        _lib.publish(W.device)
     layer.__dict__['_folded'] = (key, W, b)
     return W, b
 

@@ -26,17 +26,21 @@ def _packed(weight):
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
     hit = _cache.get(key)
     if hit is None:
-        w = weight.detach().contiguous()
-        N, K = w.shape
-        sw = occ_fold.choose_kw([w])
-        buf = torch.empty(_lib.lib().rfd_gemm_packed_bytes(N, K), dtype=torch.uint8, device=w.device)
-        with torch.cuda.device(w.device):
-            rc = _lib.lib().rfd_gemm_pack_w(N, K, sw, w.data_ptr(), buf.data_ptr(), _lib.current_stream())
-        _lib.check(rc, "rfd_gemm_pack_w")
-        hit = (buf, sw, weight)       # keep the keyed tensor alive: its address must not be reused
-        if len(_cache) > 256:
-            _cache.clear()
-        _cache[key] = hit
+        with _lib.BUILD_LOCK:
+            hit = _cache.get(key)
+            if hit is None:
+                w = weight.detach().contiguous()
+                N, K = w.shape
+                sw = occ_fold.choose_kw([w])
+                buf = torch.empty(_lib.lib().rfd_gemm_packed_bytes(N, K), dtype=torch.uint8, device=w.device)
+                with torch.cuda.device(w.device):
+                    rc = _lib.lib().rfd_gemm_pack_w(N, K, sw, w.data_ptr(), buf.data_ptr(), _lib.current_stream())
+                _lib.check(rc, "rfd_gemm_pack_w")
+                hit = (buf, sw, weight)       # keep the keyed tensor alive: its address must not be reused
+                if len(_cache) > 256:
+                    _cache.clear()
+                _lib.publish(w.device)
+                _cache[key] = hit
     return hit
 
 

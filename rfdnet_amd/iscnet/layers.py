@@ -94,12 +94,17 @@ class ResnetPointnet(nn.Module):
                    blk.fc_0.weight.data_ptr())
             c = self.__dict__.setdefault('_stack_cache', {})
             if c.get(i, (None,))[0] != key:
-                w0, ws = blk.fc_0.weight.detach(), blk.shortcut.weight.detach()
-                wide = i == 0                                   # block 0: all 2h input columns are per-point
-                first = (w0 if wide else w0[:, :h]).contiguous()
-                second = torch.cat([blk.fc_1.weight.detach(), ws if wide else ws[:, :h]], 1).contiguous()
-                c[i] = (key, first, second, None if wide else w0[:, h:].contiguous(),
-                        None if wide else ws[:, h:].contiguous())
+                from .. import _lib
+                with _lib.BUILD_LOCK:      # shared across host threads: built once, published before it is stored
+                    if c.get(i, (None,))[0] != key:
+                        w0, ws = blk.fc_0.weight.detach(), blk.shortcut.weight.detach()
+                        wide = i == 0                                   # block 0: all 2h input columns are per-point
+                        first = (w0 if wide else w0[:, :h]).contiguous()
+                        second = torch.cat([blk.fc_1.weight.detach(), ws if wide else ws[:, :h]], 1).contiguous()
+                        entry = (key, first, second, None if wide else w0[:, h:].contiguous(),
+                                 None if wide else ws[:, h:].contiguous())
+                        _lib.publish(second.device)
+                        c[i] = entry
             return (blk,) + c[i][1:]
 
         fuse_pool = gemm.pool_usable(M, h, 2 * h, T)

@@ -25,6 +25,14 @@ from . import (occupancy_net, pointnet2backbone, proposal_module,  # noqa: F401 
 from .registers import METHODS, MODULES
 
 
+class _StageFlag(Exception):
+    """status bits raised by the stages in front of the completion (internal to ISCNet.reconstruct / complete)"""
+
+    def __init__(self, status):
+        super().__init__("status %d" % status)
+        self.status = status
+
+
 @METHODS.register_module
 class ISCNet(nn.Module):
     def __init__(self, cfg):
@@ -165,32 +173,40 @@ class ISCNet(nn.Module):
         for attempt in (0, 1):
             codes = self.object_codes(end_points, proposal_features, ids, pc)
             cls = self.cls_codes(end_points, ids)
-            # the stream's status word is read HERE, before the completion: a GEMM that overflowed has clipped the
-            # codes, and a decoder run on clipped codes could raise ITS range flag, lower the decoder's scale for good
-            # and hide the GEMM's flag behind status 6.  One stream wait per scene, behind the
-            # skip-propagation stage (the MISE loop that follows waits once per round anyway).
+            # A snapshot of the stream's status word is taken HERE, before the completion, without waiting: a GEMM that
+            # overflowed has clipped the codes, and a decoder run on clipped codes could raise ITS range flag -- the
+            # completion must then neither lower the decoder's scale for good nor hide the GEMM's flag.
+            # The snapshot is read after the completion's own status read has synchronised the stream.
             with torch.cuda.device(pc.device):
-                st = _lib.stream_status_bits()
-            if st & 4 and not st & ~4 and attempt == 0 and gemm.lower_scale():
-                continue                                   # the stage again at the fallback GEMM scale
-            _lib.raise_status(st)                          # FPS exchange time-out, or an overflow at the fallback scale
+                snap = _lib.StatusSnapshot()
             if hook is not None:
                 hook(codes, cls)
-            return self.complete(codes, cls, pc.device, return_grids=return_grids)
+            try:
+                return self.complete(codes, cls, pc.device, return_grids=return_grids, before=snap)
+            except _StageFlag as e:
+                if e.status & 4 and not e.status & ~4 and attempt == 0 and gemm.lower_scale():
+                    continue                               # the stage again at the fallback GEMM scale
+                _lib.raise_status(e.status)                # FPS exchange time-out, or an overflow at the fallback scale
+                raise
 
-    def complete(self, codes, cls, device, return_grids=False):
+    def complete(self, codes, cls, device, return_grids=False, before=None):
         """Occupancy completion of the selected proposals + the status read that must follow it.
         FPS exchange time-outs and f16-range flags are reported through the stream's status word, not through
         return codes (the kernels are asynchronous): never hand back results without reading it (waits for THIS
         stream only; several scenes may be in flight, each stream has its own word).  A decoder activation beyond
         the f16 range at the default scale does not fail the scene: the completion is run again at the fallback
-        scale (the reference's fp32 decoder cannot overflow, occ_decoder.py:110-123) and only a second flag raises."""
+        scale (the reference's fp32 decoder cannot overflow, occ_decoder.py:110-123) and only a second flag raises.
+        before: a StatusSnapshot taken in front of the completion -- flags in it belong to the stages before (raised as
+        _StageFlag for reconstruct() to answer) and are looked at FIRST: the decoder's scale is not touched on their
+        account."""
         from .. import _lib
         gen = self.completion.generator
         run = gen.generate_grids if return_grids else gen.generate_mesh
         out = run(codes, cls)
         with torch.cuda.device(device):
             st = _lib.stream_status_bits()
+        if before is not None and before.read():
+            raise _StageFlag(before.read())
         if st & 2 and self.completion.decoder.lower_activation_scale():
             out = run(codes, cls)
             with torch.cuda.device(device):

@@ -91,8 +91,7 @@ class DecoderCBatchNorm(nn.Module):
         # the reference's fp32 decoder (occ_decoder.py:110-123) cannot overflow, so neither may this one fail a scene
         self.ka = occ_fold.KA
         self.check_range = True        # forward() reads the stream's status word after the launch
-        self._packed = None
-        self._packed_key = None
+        self._packed = None            # (packed stream, kw0, kw1, key)
 
     # ---- weight stream (re-packed only when the parameters change) -----------
     def _weights_key(self):
@@ -102,7 +101,13 @@ class DecoderCBatchNorm(nn.Module):
 
     def packed_weights(self):
         key = self._weights_key() + (self.kernel,)
-        if self._packed is None or key != self._packed_key:
+        hit = self._packed
+        if hit is not None and hit[3] == key:
+            return hit[:3]
+        with _lib.BUILD_LOCK:          # shared across host threads: built once, published before it is stored
+            hit = self._packed
+            if hit is not None and hit[3] == key:
+                return hit[:3]
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             fc0, fc1 = occ_fold.stacked_fc_weights(sd)
             if not fc0.is_cuda:
@@ -116,9 +121,9 @@ class DecoderCBatchNorm(nn.Module):
                 pack = _lib.lib().rfd_occ_pack_weights_w8 if self.kernel == "w8" else _lib.lib().rfd_occ_pack_weights
                 rc = pack(fc0.data_ptr(), fc1.data_ptr(), arr, kw1, packed.data_ptr(), _lib.current_stream())
             _lib.check(rc, "rfd_occ_pack_weights")
-            self._packed = (packed, kw0, kw1)
-            self._packed_key = key
-        return self._packed
+            _lib.publish(fc0.device)
+            self._packed = (packed, kw0, kw1, key)      # one tuple, one store: readers never see a half-updated pair
+        return self._packed[:3]
 
     def _fc_out_bias(self):
         b = self.fc_out.bias
@@ -138,11 +143,16 @@ class DecoderCBatchNorm(nn.Module):
             return occ_fold.fold_table(sd, z, c, kw0, kw1, ka=self.ka)
         key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
             tuple((b.data_ptr(), b._version) for b in self.buffers()) + (self.ka,)
-        if getattr(self, "_fold_key", None) != key:
-            sd = {k: v.detach() for k, v in self.state_dict().items()}
-            self._fold_consts = occ_fold.stacked_constants(sd, kw0, kw1, ka=self.ka)
-            self._fold_key = key
-        return occ_fold.fold_table_stacked(self._fold_consts, z, c)
+        hit = getattr(self, "_fold_cache", None)
+        if hit is None or hit[0] != key:
+            with _lib.BUILD_LOCK:
+                hit = getattr(self, "_fold_cache", None)
+                if hit is None or hit[0] != key:
+                    sd = {k: v.detach() for k, v in self.state_dict().items()}
+                    consts = occ_fold.stacked_constants(sd, kw0, kw1, ka=self.ka)
+                    _lib.publish(c.device)
+                    hit = self._fold_cache = (key, consts)
+        return occ_fold.fold_table_stacked(hit[1], z, c)
 
     def lower_activation_scale(self):
         """After status bit 2 (an activation * 2^ka reached the f16 limit): switch to the fallback scale, once.

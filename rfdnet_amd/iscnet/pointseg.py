@@ -182,8 +182,13 @@ class PointSeg(nn.Module):
         W, b = folded(self.conv1, self.bn1)
         c = self.__dict__.get('_head_split')
         if c is None or c[0] is not W:                       # per-point / per-proposal column halves
-            c = (W, W[:, 1024:].contiguous(), W[:, :1024].contiguous(), torch.zeros_like(b))
-            self.__dict__['_head_split'] = c
+            from .. import _lib
+            with _lib.BUILD_LOCK:      # shared across host threads: built once, published before it is stored
+                c = self.__dict__.get('_head_split')
+                if c is None or c[0] is not W:
+                    c = (W, W[:, 1024:].contiguous(), W[:, :1024].contiguous(), torch.zeros_like(b))
+                    _lib.publish(W.device)
+                    self.__dict__['_head_split'] = c
         gbias = F.linear(g, c[2], b).contiguous()                              # (B,512): conv1's global-feature share + bias
         if chain.head_usable(pointfeat, P, self.k):
             # conv1 (point-feature columns) -> conv2 -> conv3 -> conv4 in one kernel (csrc/pointseg_chain.hip)

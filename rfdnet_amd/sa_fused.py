@@ -55,14 +55,20 @@ def _packed(mlp):
     key = tuple((p.data_ptr(), p._version) for m in convs + bns for p in list(m.parameters()) + list(m.buffers()))
     hit = mlp.__dict__.get('_rfd_sa_packed')
     if hit is None or hit[0] != key:
-        out = []
-        for li, (cv, bn) in enumerate(zip(convs, bns)):
-            w, b = _fold(cv, bn)
-            K = w.shape[1]
-            korder = _korder_first(((K + 7) // 8) * 4) if li == 0 else _korder_next(K // 2)
-            out += [pack_layer(w, korder), b]
-        hit = (key, out)
-        mlp.__dict__['_rfd_sa_packed'] = hit
+        from . import _lib
+        with _lib.BUILD_LOCK:          # shared across host threads: built once, published before it is stored
+            hit = mlp.__dict__.get('_rfd_sa_packed')
+            if hit is None or hit[0] != key:
+                out = []
+                for li, (cv, bn) in enumerate(zip(convs, bns)):
+                    w, b = _fold(cv, bn)
+                    K = w.shape[1]
+                    korder = _korder_first(((K + 7) // 8) * 4) if li == 0 else _korder_next(K // 2)
+                    out += [pack_layer(w, korder), b]
+                hit = (key, out)
+                if out[0].is_cuda:
+                    _lib.publish(out[0].device)
+                mlp.__dict__['_rfd_sa_packed'] = hit
     return hit[1]
 
 

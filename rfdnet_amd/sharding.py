@@ -54,10 +54,13 @@ def numa_cpus_for_gpu(index, sys_root="/sys"):
         gpus = []
         for n in sorted(os.listdir(base), key=int):
             props = {}
-            with open(os.path.join(base, n, "properties")) as fh:
-                for line in fh:
-                    k, _, v = line.strip().partition(" ")
-                    props[k] = v
+            try:
+                with open(os.path.join(base, n, "properties")) as fh:
+                    for line in fh:
+                        k, _, v = line.strip().partition(" ")
+                        props[k] = v
+            except OSError:
+                continue        # a container sees only its own GPUs' nodes: the others are unreadable (EPERM) or empty
             if int(props.get("simd_count", "0")) > 0:
                 gpus.append(props)
         p = gpus[index]

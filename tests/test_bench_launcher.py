@@ -200,3 +200,26 @@ def test_a_rank_that_cannot_be_spawned_takes_the_started_ranks_with_it(tmp_path,
     with pytest.raises(OSError):
         sharding.launch_local_ranks(str(script), [], 2, env={"RFD_PIN_NUMA": "0"})
     assert started and started[0].poll() is not None
+
+
+def test_numa_lookup_skips_kfd_nodes_it_may_not_read(tmp_path):
+    """Inside a container only the job's own GPUs are readable under /sys/class/kfd: the other nodes' `properties`
+    raise EPERM (seen on the MI355X boxes: nodes 8, 9) or are empty.  The lookup must skip them instead of giving up
+    (round 3's version returned None there, so no rank was ever pinned on those boxes)."""
+    from rfdnet_amd import sharding
+    root = tmp_path / "sys"
+    nodes = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    for i in range(4):
+        (nodes / str(i)).mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("simd_count 0\nlocation_id 0\ndomain 0\n")      # the CPU node
+    (nodes / "1" / "properties").write_text("")                                                 # hidden GPU: empty
+    (nodes / "2" / "properties").write_text("simd_count 1024\nlocation_id 61696\ndomain 0\n") # ours: 0000:f1:00.0
+    # node 3: no properties file at all (open() raises, like EPERM)
+    d = root / "bus" / "pci" / "devices" / "0000:f1:00.0"
+    d.mkdir(parents=True)
+    (d / "numa_node").write_text("1\n")
+    n1 = root / "devices" / "system" / "node" / "node1"
+    n1.mkdir(parents=True)
+    (n1 / "cpulist").write_text("64-127,192-255\n")
+    cpus = sharding.numa_cpus_for_gpu(0, str(root))
+    assert cpus is not None and cpus[0] == 64 and cpus[-1] == 255 and len(cpus) == 128

@@ -111,3 +111,27 @@ def test_stacked_fold_equals_layerwise_fold(golden_dir):
     assert torch.equal(w, w_ref)
     # identical arithmetic per element; only the GEMM summation order may differ
     assert torch.allclose(t, t_ref, rtol=1e-5, atol=1e-5 * float(t_ref.abs().max()))
+
+
+def test_folded_layers_are_built_once_when_several_host_threads_share_a_network():
+    """bench.py runs several scenes in flight on ONE model: the lazily built caches (here: a folded conv + BatchNorm)
+    are built under rfdnet_amd._lib.BUILD_LOCK -- eight threads asking at the same moment all get the same tensors."""
+    import threading
+    import torch
+    from rfdnet_amd import fold_bn
+    conv = torch.nn.Conv1d(16, 32, 1)
+    bn = torch.nn.BatchNorm1d(32).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 1.5)
+    out, go = [None] * 8, threading.Barrier(8)
+
+    def work(i):
+        go.wait()
+        out[i] = fold_bn.folded(conv, bn)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(o[0] is out[0][0] and o[1] is out[0][1] for o in out)
+    ref = conv.weight[:, :, 0] * (bn.weight / torch.sqrt(bn.running_var + bn.eps))[:, None]
+    assert torch.allclose(out[0][0], ref.detach(), atol=1e-6)
