@@ -30,6 +30,13 @@ import sys
 import threading
 import time
 
+# Every scene in flight owns a compute stream and a copy stream.  ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4) in the order of their first use, and two streams sharing one queue serialise -- a 30-ms mesh blit then
+# holds up another scene's kernels.  Measured (profiles/r04_hw_queues.txt): 2 queues -8 %, 8-16 queues +1-2 % at three scenes
+# in flight and +3-5 % at four (which does not pay with 4 queues).  Read by the HIP runtime when it initialises, so it is set
+# before anything touches the GPU; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -73,7 +80,7 @@ def parse(argv=None):
                          "ball query): profiling runs that want the scene's own kernels only")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the one-scene-at-a-time pass after the timed region")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="scenes reconstructed concurrently per GPU (one host thread + HIP stream + model "
                          "replica each); a step = one such batch")
     ap.add_argument("--batch", type=int, default=1,

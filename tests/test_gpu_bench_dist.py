@@ -28,5 +28,7 @@ def test_bench_over_rccl_world_size_one(hip):
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 1 and out["config"]["scenes_failed"] == 0 and out["config"]["scenes_done"] == 3
+    # one step = one batch of the scenes in flight per GPU (bench.py's default; 4 since round 4)
+    assert out["n_gpus"] == 1 and out["config"]["scenes_failed"] == 0
+    assert out["config"]["scenes_done"] == out["config"]["scenes_in_flight_per_gpu"] == 4
     assert out["value"] > 1.0 and out["roofline"]["achieved"] > 100.0
