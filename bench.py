@@ -774,12 +774,14 @@ def main(argv=None):
                  "and let bench.py spawn its own ranks)" % (args.gpus, world, args.gpus))
     cls = StubBackend if os.environ.get("RFD_BENCH_STUB") == "1" else \
         StressBackend if args.config == "stress" else HipBackend
+    all_cpus = None
     if cls is not StubBackend and os.environ.get("RFD_PIN_NUMA", "1") != "0" and not os.environ.get("RFD_BENCH_ONE_DEVICE"):
         # host threads, pinned mesh buffers (first touch) and the HIP runtime's helper threads on the CPUs of THIS GPU's
         # NUMA node -- also with one rank, and when torch.distributed.run (not sharding.launch_local_ranks) started the
         # ranks.  +1-2 % scenes/s on a two-socket box (profiles/r04_numa_prime.txt).
         cpus = sharding.pin_cpus_for_rank(local_rank)
         if cpus:
+            all_cpus = os.sched_getaffinity(0)
             sharding._pin(cpus)
     be = cls(args, rank, local_rank, world)
     dist = None
@@ -852,6 +854,13 @@ def main(argv=None):
             out["single_scene"] = {"scenes_in_flight": 1, "ms_per_scene": 1e3 * single,
                                    "scenes_per_s": 1.0 / single}
         if world == 1 and not args.no_cpu_baseline and be.name != "stub":
+            if all_cpus:
+                # the CPU legs (parity checker, CPU baseline) get EVERY host core back: the NUMA pinning above is for the
+                # GPU path's host threads; threads created from here on (OpenMP, torch intra-op) inherit the full mask
+                try:
+                    os.sched_setaffinity(0, all_cpus)
+                except OSError:
+                    pass
             from oracle import cpu_baseline                       # the checker's CPU port, timed beside
             if stress:
                 out["cpu_baseline"] = cpu_baseline.run_decoder_only()

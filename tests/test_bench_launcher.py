@@ -42,7 +42,9 @@ def test_single_process_default():
     p = run_bench(["--steps", "2", "--warmup", "0", "--no-cpu-baseline"])
     assert p.returncode == 0, p.stderr
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
-    assert out["n_gpus"] == 1 and out["config"]["scenes_failed"] == 0 and out["config"]["scenes_done"] == 6
+    # two steps of the default four scenes in flight
+    assert out["n_gpus"] == 1 and out["config"]["scenes_failed"] == 0 and out["config"]["scenes_done"] == 8
+    assert out["config"]["scenes_in_flight_per_gpu"] == 4
 
 
 def test_world_size_mismatch_fails_loudly():
