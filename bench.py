@@ -373,6 +373,41 @@ class HipBackend(object):
     def final_check(self):
         self._lib.device_status()
         self.selfcheck = self.decoder_selfcheck(self.dec if hasattr(self, "dec") else self.nets[0].completion.decoder)
+        self.alone = self.decoder_alone()
+
+    def decoder_alone(self):
+        """After the timed region, nothing else on the GPU: MISE round 0 of one scene (every proposal's level-0 lattice,
+        the shared query list) decoded three times -- the same kernel, shape and launch path as the timed region's round-0
+        launches, so `roofline.per_round[0]` can be read against it (inside a scene the launch shares the chip with the
+        other scenes' kernels; its event-bracketed time is the kernel's own plus what it lent out)."""
+        torch = self.torch
+        if not getattr(self, "nets", None):
+            return None                       # the stress configuration IS the decoder alone
+        net = self.nets[0]
+        gen = net.completion.generator
+        if gen.upsampling_steps == 0:
+            return None
+        dec = net.completion.decoder
+        K = 256
+        g = torch.Generator(device=self.device).manual_seed(7)
+        with torch.no_grad():
+            c = torch.randn(K, dec.blocks[0].bn_0.c_dim, device=self.device, generator=g)
+            table, fcp = dec.fold(torch.zeros(K, dec.z_dim, device=self.device), c)
+            pts, lin, tile_prop, tile_src, total = gen._round0(gen.resolution0, gen.upsampling_steps, 1 + gen.padding, K,
+                                                               self.device)
+            orig = self.timers[0]._orig
+            orig(pts, tile_prop, table, fcp, tile_src=tile_src)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                orig(pts, tile_prop, table, fcp, tile_src=tile_src)
+            e1.record()
+            e1.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        tf = total * FLOP_PER_QUERY / (ms * 1e-3) / 1e12
+        return {"what": "MISE round 0 of one scene (256 proposals x %d lattice points) decoded alone after the timed region"
+                        % (total // K), "avg_launch_ms": ms, "achieved": tf, "frac": tf / MFMA_PEAK_TFLOPS}
 
     def decoder_selfcheck(self, dec):
         """After the timed region: the same multi-proposal ragged launch four times -- the results must be
@@ -841,6 +876,7 @@ def main(argv=None):
                          if bpq else None,
                          "launches": int(dec_launches),
                          "per_round": be.per_round() if hasattr(be, "per_round") else None,
+                         "alone": getattr(be, "alone", None),
                          "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
                          "algorithmic_flop_per_launch": dec_pts * FLOP_PER_QUERY / dec_launches if dec_launches else None,
                          "note": "algorithmic FLOPs (1 312 768 per query point) over HIP-event time of the decoder "
