@@ -64,8 +64,8 @@ CONFIGS = {
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)       # 32 scenes at four in flight: ~1.6 s timed
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline")
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--resolution0", type=int, default=None)
