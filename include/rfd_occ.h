@@ -196,8 +196,15 @@ int rfd_occ_decode_scatter_w8(int n_tiles, const float *pts, const int *tile_pro
  * each batch half of what is left, single tiles at the end; *begin == *end == n_tiles past the last chunk.  Host-side
  * view of the schedule for tests and tools; the kernel evaluates the same function. */
 int rfd_occ_chunk_range(int k, int n_tiles, int n_workgroups, int *begin, int *end);
+/* Launch shape of the eight-wave decoder; every argument >= 0 sets, < 0 leaves unchanged.  The default (0, 0, 0) =
+ * persistent grid of one workgroup per CU with run-time chunk claiming is what ships; the others are the A/B controls
+ * of the tests and of profiles/r04_*.txt, bit-identical in their results and slower: static_partition != 0 = rounds 1-3's
+ * equal runs of consecutive tiles per workgroup; cus = n: a persistent grid of n < num_cu workgroups; chunk_cap = c
+ * (1..255): NOT persistent, one workgroup per chunk of at most c tiles.  Initial values come ONCE from the environment
+ * (RFD_DECODER_STATIC, RFD_DECODER_CUS, RFD_DECODER_CHUNK); nothing reads the environment on the launch path. */
+int rfd_occ_set_launch_shape(int static_partition, int cus, int chunk_cap);
 /* The same schedule with no chunk larger than max_chunk tiles (max_chunk = 0: uncapped) -- the shape of the
- * one-workgroup-per-chunk launch (RFD_DECODER_CHUNK); *n_chunks (optional) = number of non-empty chunks = its grid. */
+ * one-workgroup-per-chunk launch (rfd_occ_set_launch_shape's chunk_cap); *n_chunks (optional) = number of non-empty chunks = its grid. */
 int rfd_occ_chunk_range_capped(int k, int n_tiles, int n_workgroups, int max_chunk, int *begin, int *end,
                                int *n_chunks);
 

@@ -125,11 +125,11 @@ int rfd_furthest_point_sampling_gather(int b, int n, int m,
 
 /* ---- diagnostics --------------------------------------------------------- */
 const char *rfd_last_error_string(void);
-/* Device-side status words of the persistent kernels (bit 0: FPS exchange spin
- * limit; bit 1: occupancy decoder, bit 2: split-precision GEMMs -- an activation
- * beyond the f16 range at the current scale).  One word per stream (64 slots per
- * device; slot 0 is the null stream's and the overflow slot).  rfd_device_status
- * synchronises the DEVICE and returns / clears the OR of all words.  0 = OK. */
+/* Device-side status words of the persistent kernels (bit 0: a multi-workgroup FPS launch
+ * ABORTED on its exchange time-out, see rfd_fps_set_timeout_ms; bit 1: occupancy decoder,
+ * bit 2: split-precision GEMMs -- an activation beyond the f16 range at the current scale).
+ * One word per stream (64 slots per device; slot 0 is the null stream's and the overflow slot).
+ * rfd_device_status synchronises the DEVICE and returns / clears the OR of all words.  0 = OK. */
 int rfd_device_status(void);
 /* The word of `stream` only, after waiting for that stream (other streams keep
  * running and keep their own flags); cleared when reported. */
@@ -140,6 +140,25 @@ int rfd_stream_status_snapshot(void *stream, unsigned *host_word);
 /* Give the status slot of `stream` back (callers that create a stream per scene);
  * waits for the stream and returns its pending flags.  Not owning a slot is fine. */
 int rfd_release_stream(void *stream);
+/* Multi-workgroup furthest point sampling (n > 4096 points per scene: the scene is spread over G <= 64 workgroups
+ * that exchange their candidates every round) needs its G workgroups resident together.  Where they cannot be -- a
+ * CU-masked stream, a partitioned GPU, another process's persistent kernel holding the CUs -- the launch does NOT
+ * hang: a workgroup that has polled `ms` milliseconds (wall clock; default 500, or RFD_FPS_TIMEOUT_MS at load) for
+ * one round's candidates raises the launch's sticky abort word, every workgroup of the launch -- running, or
+ * dispatched only later -- leaves at once, status bit 0 is raised on the stream and idxs keeps the caller's
+ * zero-fill beyond the round reached.  The reference's answer to a launch that cannot run is to fail fast as well
+ * (cuda_utils.h:30-39: message + exit); here the host raises and the device stays usable.  Returns the previous
+ * value; ms <= 0 restores the default. */
+int rfd_fps_set_timeout_ms(int ms);
+/* Points per thread of the multi-workgroup FPS kernel (5, 8, 10, 16, 20, 32, 40, 64; 0 = the launcher's own choice,
+ * 10 at 80 000 points = 32 workgroups).  Geometry sweeps (tools/fps_sweep.py) and tests; results never depend on
+ * it.  Returns the previous value, -2 for a value that is not instantiated. */
+int rfd_fps_set_geometry(int points_per_thread);
+/* A HIP stream confined to compute units [first_cu, first_cu + n_cus) of the current device
+ * (hipExtStreamCreateWithCUMask); the caller destroys it with rfd_stream_destroy.  Not used by the product path:
+ * it is how tests/test_gpu_fps_abort.py makes a launch that cannot be co-resident. */
+int rfd_stream_create_cu_mask(int first_cu, int n_cus, void **stream);
+int rfd_stream_destroy(void *stream);
 /* "gfx950" etc. of the code object actually loaded. */
 const char *rfd_build_arch(void);
 

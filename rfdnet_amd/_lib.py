@@ -38,6 +38,11 @@ SIGNATURES = {
     "rfd_occ_decode_scatter_w8": [_i, _f, _f, _f, _f, _f, _f, _f, _fl, _f, _f, _f, C.c_longlong, _i, _f],
     "rfd_occ_chunk_range": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "rfd_occ_chunk_range_capped": [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "rfd_occ_set_launch_shape": [_i, _i, _i],
+    "rfd_fps_set_timeout_ms": [_i],
+    "rfd_fps_set_geometry": [_i],
+    "rfd_stream_create_cu_mask": [_i, _i, C.POINTER(C.c_void_p)],
+    "rfd_stream_destroy": [_f],
     "rfd_make_grid_points": [_i, _fl, _fl, _fl, _f, _i, _f],
     "rfd_mise_init": [_i, _i, _i, _f, _f, _f],
     "rfd_mise_count": [_i, _i, _i, _f, _f, _f],
@@ -145,7 +150,8 @@ def _raise_status(st):
         raise RfdHipError("rfd_device_status failed")
     msgs = []
     if st & 1:
-        msgs.append("FPS inter-workgroup exchange timed out")
+        msgs.append("furthest point sampling aborted: its workgroups were not resident together within the "
+                    "exchange time-out (CU-masked stream / partitioned or oversubscribed GPU?)")
     if st & 2:
         msgs.append("occupancy decoder: activation exceeded the f16 range")
     if st & 4:
@@ -170,27 +176,48 @@ def stream_status_bits():
     return st
 
 
-_snap_bufs = {}
+_snap_pool = []
+_snap_lock = _threading.Lock()
 
 
 class StatusSnapshot(object):
-    """the current stream's status word as it stood when the snapshot was taken; read() after the stream has been
-    synchronised (by the caller's next status read, a `.cpu()`, ...)"""
+    """The current stream's status word as it stood when the snapshot was taken (and reset, in stream order).
+    Every snapshot has a pinned word of its own (from a small pool it goes back to at the first read()), so a second
+    snapshot on the same stream cannot overwrite the first one's flags before they are read, and
+    read() waits for the snapshot's own event: the caller need not have synchronised the stream."""
 
     def __init__(self):
         import torch
         s = torch.cuda.current_stream()
-        key = (torch.cuda.current_device(), s.cuda_stream, _threading.get_ident())
-        buf = _snap_bufs.get(key)
+        with _snap_lock:
+            buf = _snap_pool.pop() if _snap_pool else None
         if buf is None:
-            buf = _snap_bufs[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.buf = buf
+            buf = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.buf, self.value = buf, None
         st = lib().rfd_stream_status_snapshot(s.cuda_stream, buf.data_ptr())
         if st < 0:
             raise RfdHipError("rfd_stream_status_snapshot failed")
+        self.event = torch.cuda.Event()
+        self.event.record(s)
 
     def read(self):
-        return int(self.buf[0]) & 0xffffffff
+        if self.value is None:
+            self.event.synchronize()
+            self.value = int(self.buf[0]) & 0xffffffff
+            with _snap_lock:
+                if len(_snap_pool) < 64:
+                    _snap_pool.append(self.buf)
+            self.buf = None
+        return self.value
+
+
+def cu_masked_stream(first_cu, n_cus):
+    """torch stream over a HIP stream confined to CUs [first_cu, first_cu + n_cus) (tests; see rfd_pointnet2.h).
+    Destroy with lib().rfd_stream_destroy(stream.cuda_stream)."""
+    import torch
+    h = C.c_void_p()
+    check(lib().rfd_stream_create_cu_mask(first_cu, n_cus, C.byref(h)), "rfd_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(h.value)
 
 
 def release_stream(stream=None):

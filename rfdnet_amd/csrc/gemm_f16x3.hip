@@ -627,10 +627,12 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
     if (rc0) return rc0;
   }
   g.status = rfd_status_word(ws0, (hipStream_t)stream);
+  // RFD_GEMM_TILE_ONLY: A/B switch of tools/gemm_bench.py (the tile kernel for every shape), read once per process
+  static const bool tile_only = getenv("RFD_GEMM_TILE_ONLY") != nullptr;
   const bool aligned = !(ldc & 3) && !(ldr & 3) && !((uintptr_t)C & 15) && !((uintptr_t)R & 15) &&
                        !((uintptr_t)bias & 15) && !((uintptr_t)gbias & 15);
   if (M % RM == 0 && N % RN == 0 && N <= RFD_ZEROS_FLOATS && K % 128 == 0 && aligned &&
-      ((!gbias && !pool_max) || g.rows_per_group % 64 == 0) && getenv("RFD_GEMM_TILE_ONLY") == nullptr) {
+      ((!gbias && !pool_max) || g.rows_per_group % 64 == 0) && !tile_only) {
     RfdWorkspace *ws;
     int rc = rfd_get_workspace(&ws);
     if (rc) return rc;

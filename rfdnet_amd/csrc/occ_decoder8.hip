@@ -20,67 +20,11 @@
 #include <type_traits>
 #include "../../include/rfd_occ.h"
 
-// Timing-only side builds (tools/ab/, results are WRONG on purpose): what do the LDS fragment
-// reads and the LDS-DMA weight stream cost?  profiles/r02_decoder_ablation.txt: -15 % / -10 %.
-#ifndef DEC8_NOREAD
-#define DEC8_NOREAD 0
-#endif
-#ifndef DEC8_NODMA
-#define DEC8_NODMA 0
-#endif
-// Build switches (tools/ab/build_variants.py; profiles/r03_decoder_hazard.txt, profiles/r03_decoder_ablation.txt):
-//   DEC8_ROT   1 = weight-fragment prefetch through three rotating register sets, k-steps fenced (shipped);
-//              0 = round 2's compiler-placed two-set prefetch (kept as the control of the ISA audit and for A/B)
-//   DEC8_SB    1 = sched_barrier at every k-step boundary and in front of every barrier (part of DEC8_ROT 1)
-//   DEC8_FENCE 1 = round 2's scheduling fence after every LDS-DMA issue (DEC8_ROT 0 only)
-//   DEC8_PRIO  1 = static s_setprio 1 for waves 4-7 (the arrangement that exposed round 2's failure; not shipped)
-//   DEC8_DMA_AUX cache policy bits of the LDS-DMA weight stream (aux operand of global_load_lds; 2 = nt measured
-//              -0.3 % .. -0.4 % kernel time but 1093 instead of 15 B of HBM traffic per query point -- the hint evicts
-//              the 2.6-MB stream every workgroup re-reads once per tile from L2 -- so it is NOT shipped:
-//              profiles/r03_decoder_traffic_nt.txt)
-#ifndef DEC8_ROT
-#define DEC8_ROT 1
-#endif
-#ifndef DEC8_FENCE
-#define DEC8_FENCE 0
-#endif
-#ifndef DEC8_SB
-#define DEC8_SB 1
-#endif
-#ifndef DEC8_PRIO
-#define DEC8_PRIO 0
-#endif
-#ifndef DEC8_DMA_AUX
-#define DEC8_DMA_AUX 0
-#endif
-#ifndef DEC8_WLO_BITS
-#define DEC8_WLO_BITS 11
-#endif
-// Round 4 energy ledger (profiles/r04_decoder_energy.txt), timing-only side builds on REAL (non-zero) operands:
-//   DEC8_THIN  1 = weight-fragment LDS reads thinned to 1/8: every k-step of an 8-step sequence reuses the registers
-//              of its k-step 0 (results wrong; separates LDS-read stalls + energy from multiplier energy)
-//   DEC8_BF16C 2 = both correction products (W_hi x a_lo, W_lo x a_hi) issued as v_mfma_f32_16x16x32_bf16 on the same
-//              register bits (W_lo packed as bf16 values), 1 = W_lo x a_hi only; prices 8-bit against 11-bit
-//              significands in the multiplier arrays.  f16 bits read as bf16 can be huge, so the re-typed products go
-//              to two JUNK accumulators instead of the data path (a NaN would be rectified to 0 and zero the
-//              operands of every later layer); the data path keeps the hi x hi term.  Results wrong on purpose.
-//   DEC8_JUNK  1 = control of the above: the corrections stay f16 MFMAs but also go to the junk accumulators (same
-//              dependency structure as DEC8_BF16C 2, shipped arithmetic types)
-#ifndef DEC8_THIN
-#define DEC8_THIN 0
-#endif
-// default launch shape of the eight-wave decoder: 0 = persistent grid + run-time claiming; c > 0 = one workgroup per
-// chunk of at most c tiles (RFD_DECODER_CHUNK overrides it per process)
-#ifndef RFD_OCC_DEFAULT_CHUNK
-#define RFD_OCC_DEFAULT_CHUNK 0
-#endif
-#ifndef DEC8_BF16C
-#define DEC8_BF16C 0
-#endif
-#ifndef DEC8_JUNK
-#define DEC8_JUNK 0
-#endif
-
+// This file is the shipped kernel and nothing else.  The timing-only side builds of rounds 2-4 (operands zeroed,
+// weight-fragment reads thinned, correction products re-typed, static wave priorities, round 2's two-set prefetch ...:
+// results WRONG on purpose) live in tools/ab/dec8_ablation.patch, which tools/ab/build_variants.py applies to a
+// scratch copy of this source; tests/test_isa_audit.py checks that the patch still applies and that the patched
+// source built without any switch is this kernel, instruction for instruction.
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -179,37 +123,12 @@ __global__ void pack8_kernel(const float *__restrict__ fc0_w, const float *__res
   const float w = ldexpf(W[(size_t)out_ch * H + in_ch], kw);
   const _Float16 hi = (_Float16)w;
   _Float16 lo = (_Float16)(w - (float)hi);
-#if DEC8_WLO_BITS < 11
-  // experiment (profiles/r03_decoder_ablation.txt): the matrix cores' power depends on the operand bits that toggle;
-  // keep only the top DEC8_WLO_BITS significand bits of the correction fragments (0 = no w_lo at all)
-  {
-    unsigned short b = __builtin_bit_cast(unsigned short, lo);
-    b = DEC8_WLO_BITS == 0 ? (unsigned short)0 : (unsigned short)(b & (0xffffu << (11 - DEC8_WLO_BITS)));
-    lo = __builtin_bit_cast(_Float16, b);
-  }
-#endif
-#if DEC8_BF16C
-  if (s != 0) {          // W_lo as bf16 (round to nearest even on the fp32 bit pattern)
-    const float r = w - (float)hi;
-    unsigned u = __builtin_bit_cast(unsigned, r);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    reinterpret_cast<unsigned short *>(packed)[e] = (unsigned short)(u >> 16);
-    return;
-  }
-#endif
   packed[e] = s == 0 ? hi : lo;
 }
 
 __device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-#if DEC8_BF16C
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4 mfma16b(half8 a, half8 b, f32x4 c) {       // the same registers read as bf16
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
-}
-#endif
-
 __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
   unsigned r;
   asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -255,18 +174,13 @@ __device__ __forceinline__ void dma_piece8(const half8 *__restrict__ packed, uns
                                            int wave, int lane) {
   const int frag = wave * 4 + j;
   const int hs = h >= N_HALVES ? h - N_HALVES : h;
-#if DEC8_ROT == 0
-  __builtin_amdgcn_global_load_lds((gbl_void *)(packed + ((size_t)hs * HALF_FRAGS + frag) * 64 + lane),
-                                   (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, DEC8_DMA_AUX);
-#else
   // wave-uniform part computed apart from the lane part (SGPR pair + one 32-bit lane offset; no reassociation into a
   // per-piece 64-bit VGPR sum chain)
   unsigned long long b64 = (unsigned long long)packed + ((size_t)hs * HALF_FRAGS + frag) * 1024;
   asm("" : "+s"(b64));
   const char *base = reinterpret_cast<const char *>(b64);
   __builtin_amdgcn_global_load_lds((gbl_void *)(base + (unsigned)(lane * 16)),
-                                   (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, DEC8_DMA_AUX);
-#endif
+                                   (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, 0);
 }
 
 // ---- weight-fragment prefetch with PROVABLY disjoint destinations --------------------------------------------
@@ -308,24 +222,15 @@ __device__ __forceinline__ void keep_alive(const Frag4 &a) {
 
 template <int OFF>
 __device__ __forceinline__ void frag_issue(Frag4 &d, const half8 *base) {
-#if DEC8_NOREAD
-  (void)base;
-  d.h0 = d.l0 = d.h1 = d.l1 = half8{};
-#else
   const half8 *w = base + OFF / 16;
   d.h0 = w[0];
   d.l0 = w[64];
   d.h1 = w[128];
   d.l1 = w[192];
-#endif
 }
 
 // Nothing is scheduled across a k-step boundary (see above).
-__device__ __forceinline__ void step_fence() {
-#if DEC8_SB
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+__device__ __forceinline__ void step_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -354,37 +259,13 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g4 = 4 * (lane >> 4), n = lane & 15;
   unsigned amax16 = 0u;
-  // the two correction products of the three-term scheme; `ch` = which of the two interleaved accumulator chains
-#if DEC8_BF16C || DEC8_JUNK
-  f32x4 junk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#endif
-  auto corr_hl = [&](f32x4 &acc, int ch, const half8 &wh, const half8 &xl) {      // W_hi x a_lo
-#if DEC8_BF16C == 2
-    junk[ch] = mfma16b(wh, xl, junk[ch]);
-#elif DEC8_JUNK
-    junk[ch] = mfma16(wh, xl, junk[ch]);
-#else
-    (void)ch;
-    acc = mfma16(wh, xl, acc);
-#endif
-  };
-  auto corr_lh = [&](f32x4 &acc, int ch, const half8 &wl, const half8 &xh) {      // W_lo x a_hi
-#if DEC8_BF16C
-    junk[ch] = mfma16b(wl, xh, junk[ch]);
-#elif DEC8_JUNK
-    junk[ch] = mfma16(wl, xh, junk[ch]);
-#else
-    (void)ch;
-    acc = mfma16(wl, xh, acc);
-#endif
-  };
+  // the two correction products of the three-term scheme
+  auto corr_hl = [&](f32x4 &acc, const half8 &wh, const half8 &xl) { acc = mfma16(wh, xl, acc); };      // W_hi x a_lo
+  auto corr_lh = [&](f32x4 &acc, const half8 &wl, const half8 &xh) { acc = mfma16(wl, xh, acc); };      // W_lo x a_hi
   // NO static priority in the shipped build, and tests/test_isa_audit.py refuses one: unequal priorities of a SIMD's
   // two waves are the one necessary condition of round 2's wrong 16-point groups that is understood (the rest is code
   // layout and the timing of the partner wave's path: profiles/r03_decoder_hazard.txt sections 7-9), and they buy nothing
-  // (+-0.3 %).  DEC8_PRIO exists for the side builds that put the priority back on purpose (tools/ab/).
-#if DEC8_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
+  // (+-0.3 %).
 
   // claim != nullptr: chunks handed out dynamically (see chunk_range); nullptr: rounds 1-3's static partition
   // (RFD_DECODER_STATIC=1, kept as the A/B control)
@@ -470,9 +351,7 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
     // code's LDS bursts and MFMAs; on the failing binary a barrier here cures it (0/4 against 4/4 for the same bytes
     // without it: profiles/r03_decoder_hazard.txt section 8).  The shipped build has no priorities and never showed
     // the fault, so this is a belt: one barrier per tile, next to ~45 others.
-#if !defined(DEC8_NO_PROLOGUE_BARRIER)      // (the positive control of tools/audit_prologue_lds.py builds without it)
-    __syncthreads();
-#endif
+    __syncthreads();      // (the positive control of tools/audit_prologue_lds.py is a side build without it)
 
     half8 ahi[8], alo[8];
     for (int blk = 0; blk < NB; ++blk) {
@@ -480,7 +359,6 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
       // ---- block input a' = relu(S0' H' + T0'), fused with fc_0 of output block 0: k-step ks
       // needs only channel tiles 2ks, 2ks+1, so k-step ks+1 is converted under its MFMAs
       f32x4 acc_cur[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#if DEC8_ROT
       {
         const half8 *a0 = reinterpret_cast<const half8 *>(s_slots + ((2 * blk * 8) & 3) * HALF_BYTES) + lane;
         Frag4 fs[3];
@@ -491,49 +369,22 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
           step_fence();
           if constexpr (ks < 7) {
-            if (DEC8_THIN) nxt = cur;
-            else frag_issue<4096 * (ks + 1)>(nxt, a0);
+            frag_issue<4096 * (ks + 1)>(nxt, a0);
           }
           if constexpr (ks < 7)
             act_kstep<X3>(Hs[2 * ks + 2], Hs[2 * ks + 3], S0, T0, 32 * (ks + 1) + g4, ahi[ks + 1], alo[ks + 1], amax16);
           acc_cur[0] = mfma16(cur.h0, ahi[ks], acc_cur[0]);
           acc_cur[1] = mfma16(cur.h1, ahi[ks], acc_cur[1]);
           if (X3) {
-            corr_hl(acc_cur[0], 0, cur.h0, alo[ks]);
-            corr_hl(acc_cur[1], 1, cur.h1, alo[ks]);
-            corr_lh(acc_cur[0], 0, cur.l0, ahi[ks]);
-            corr_lh(acc_cur[1], 1, cur.l1, ahi[ks]);
+            corr_hl(acc_cur[0], cur.h0, alo[ks]);
+            corr_hl(acc_cur[1], cur.h1, alo[ks]);
+            corr_lh(acc_cur[0], cur.l0, ahi[ks]);
+            corr_lh(acc_cur[1], cur.l1, ahi[ks]);
           }
           if constexpr (ks == 0) keep_alive(cur);
           else keep_alive(cur, prv);
         });
       }
-#else
-      {
-        const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * blk * 8) & 3) * HALF_BYTES) + lane;
-        act_kstep<X3>(Hs[0], Hs[1], S0, T0, g4, ahi[0], alo[0], amax16);
-        half8 n0h = w[0], n0l = w[64], n1h = w[128], n1l = w[192];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const half8 w0h = n0h, w0l = n0l, w1h = n1h, w1l = n1l;
-          if (ks < 7) {     // next k-step's fragments: LDS latency under this step's MFMAs
-            n0h = w[(4 * ks + 4) * 64];
-            n0l = w[(4 * ks + 5) * 64];
-            n1h = w[(4 * ks + 6) * 64];
-            n1l = w[(4 * ks + 7) * 64];
-            act_kstep<X3>(Hs[2 * ks + 2], Hs[2 * ks + 3], S0, T0, 32 * (ks + 1) + g4, ahi[ks + 1], alo[ks + 1], amax16);
-          }
-          acc_cur[0] = mfma16(w0h, ahi[ks], acc_cur[0]);
-          acc_cur[1] = mfma16(w1h, ahi[ks], acc_cur[1]);
-          if (X3) {
-            acc_cur[0] = mfma16(w0h, alo[ks], acc_cur[0]);
-            acc_cur[1] = mfma16(w1h, alo[ks], acc_cur[1]);
-            acc_cur[0] = mfma16(w0l, ahi[ks], acc_cur[0]);
-            acc_cur[1] = mfma16(w1l, ahi[ks], acc_cur[1]);
-          }
-        }
-      }
-#endif
       step_fence();
       __syncthreads();
 
@@ -544,19 +395,9 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
         half8 bhi, blo;
         act_kstep<X3>(acc_cur[0], acc_cur[1], S1, T1, 32 * mb + g4, bhi, blo, amax16);
         auto issue_dma = [&](int j) {          // piece j (0..7) of this slab's two halves
-#if DEC8_NODMA
-          (void)j;
-#else
           const int h = 2 * c + 3 + (j >> 2);
           if (h < N_HALVES || has_next) dma_piece8(packed, s_slots, h, j & 3, wave, lane);
-#if DEC8_FENCE
-          // round 2's scheduling fence (the one change that made the static-priority build's wrong 16-point
-          // groups disappear then); superseded by the rotating fragment sets, kept for A/B
-          asm volatile("s_nop 0" ::: "memory");
-#endif
-#endif
         };
-#if DEC8_ROT
         // ---- phase A: fc_0 block mb+1 (two accumulator chains) with this iteration's LDS-DMA pieces in
         // between; phase B: H'[t] += fc_1[16t.., slab mb] a2', sixteen accumulators, two chains at a time.
         // ONE sequence of 16 k-steps for the fragment rotation: step 7 of phase A prefetches phase B's first set.
@@ -570,8 +411,7 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
             Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
             step_fence();
             if constexpr (ks < 7) {
-              if (DEC8_THIN) nxt = cur;
-              else frag_issue<4096 * (ks + 1)>(nxt, aA);
+              frag_issue<4096 * (ks + 1)>(nxt, aA);
             } else {
               frag_issue<0>(nxt, aB);
             }
@@ -579,10 +419,10 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
             acc_next[0] = mfma16(cur.h0, ahi[ks], acc_next[0]);
             acc_next[1] = mfma16(cur.h1, ahi[ks], acc_next[1]);
             if (X3) {
-              corr_hl(acc_next[0], 0, cur.h0, alo[ks]);
-              corr_hl(acc_next[1], 1, cur.h1, alo[ks]);
-              corr_lh(acc_next[0], 0, cur.l0, ahi[ks]);
-              corr_lh(acc_next[1], 1, cur.l1, ahi[ks]);
+              corr_hl(acc_next[0], cur.h0, alo[ks]);
+              corr_hl(acc_next[1], cur.h1, alo[ks]);
+              corr_lh(acc_next[0], cur.l0, ahi[ks]);
+              corr_lh(acc_next[1], cur.l1, ahi[ks]);
             }
             if constexpr (ks == 0) keep_alive(cur);
             else keep_alive(cur, prv);
@@ -598,16 +438,15 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
           Frag4 &cur = fs[ks % 3], &nxt = fs[(ks + 1) % 3], &prv = fs[(ks + 2) % 3];
           step_fence();
           if constexpr (tp < 7) {
-            if (DEC8_THIN) nxt = cur;
-            else frag_issue<4096 * (tp + 1)>(nxt, aB);
+            frag_issue<4096 * (tp + 1)>(nxt, aB);
           }
           Hs[2 * tp] = mfma16(cur.h0, bhi, Hs[2 * tp]);
           Hs[2 * tp + 1] = mfma16(cur.h1, bhi, Hs[2 * tp + 1]);
           if (X3) {
-            corr_hl(Hs[2 * tp], 0, cur.h0, blo);
-            corr_hl(Hs[2 * tp + 1], 1, cur.h1, blo);
-            corr_lh(Hs[2 * tp], 0, cur.l0, bhi);
-            corr_lh(Hs[2 * tp + 1], 1, cur.l1, bhi);
+            corr_hl(Hs[2 * tp], cur.h0, blo);
+            corr_hl(Hs[2 * tp + 1], cur.h1, blo);
+            corr_lh(Hs[2 * tp], cur.l0, bhi);
+            corr_lh(Hs[2 * tp + 1], cur.l1, bhi);
           }
           // tp == 0: the set before this one is phase A's step 7 (mb < 7) or nothing (mb == 7, behind a barrier)
           if constexpr (tp == 0) {
@@ -617,63 +456,6 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
             keep_alive(cur, prv);
           }
         });
-#else
-        // ---- phase A: fc_0 block mb+1 (two accumulator chains) with this iteration's LDS-DMA
-        // pieces in between
-        auto phase_a = [&]() {
-        if (mb < 7) {
-          const half8 *w = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 2) & 3) * HALF_BYTES) + lane;
-          half8 n0h = w[0], n0l = w[64], n1h = w[128], n1l = w[192];
-#pragma unroll
-          for (int ks = 0; ks < 8; ++ks) {
-            const half8 w0h = n0h, w0l = n0l, w1h = n1h, w1l = n1l;
-            if (ks < 7 && !DEC8_NOREAD) {
-              n0h = w[(4 * ks + 4) * 64];
-              n0l = w[(4 * ks + 5) * 64];
-              n1h = w[(4 * ks + 6) * 64];
-              n1l = w[(4 * ks + 7) * 64];
-            }
-            issue_dma(ks);
-            acc_next[0] = mfma16(w0h, ahi[ks], acc_next[0]);
-            acc_next[1] = mfma16(w1h, ahi[ks], acc_next[1]);
-            if (X3) {
-              acc_next[0] = mfma16(w0h, alo[ks], acc_next[0]);
-              acc_next[1] = mfma16(w1h, alo[ks], acc_next[1]);
-              acc_next[0] = mfma16(w0l, ahi[ks], acc_next[0]);
-              acc_next[1] = mfma16(w1l, ahi[ks], acc_next[1]);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) issue_dma(j);
-        }
-        };
-        // ---- phase B: H'[t] += fc_1[16t.., slab mb] a2', sixteen accumulators, two chains at a time
-        auto phase_b = [&]() {
-          const half8 *w2 = reinterpret_cast<const half8 *>(s_slots + ((2 * c + 1) & 3) * HALF_BYTES) + lane;
-          half8 n0h = w2[0], n0l = w2[64], n1h = w2[128], n1l = w2[192];
-#pragma unroll
-          for (int tp = 0; tp < 8; ++tp) {
-            const half8 c0h = n0h, c0l = n0l, c1h = n1h, c1l = n1l;
-            if (tp < 7 && !DEC8_NOREAD) {
-              n0h = w2[(4 * tp + 4) * 64];
-              n0l = w2[(4 * tp + 5) * 64];
-              n1h = w2[(4 * tp + 6) * 64];
-              n1l = w2[(4 * tp + 7) * 64];
-            }
-            Hs[2 * tp] = mfma16(c0h, bhi, Hs[2 * tp]);
-            Hs[2 * tp + 1] = mfma16(c1h, bhi, Hs[2 * tp + 1]);
-            if (X3) {
-              Hs[2 * tp] = mfma16(c0h, blo, Hs[2 * tp]);
-              Hs[2 * tp + 1] = mfma16(c1h, blo, Hs[2 * tp + 1]);
-              Hs[2 * tp] = mfma16(c0l, bhi, Hs[2 * tp]);
-              Hs[2 * tp + 1] = mfma16(c1l, bhi, Hs[2 * tp + 1]);
-            }
-          }
-        };
-        phase_a();
-        phase_b();
-#endif
         // (running the two phases in opposite order on the two waves of a SIMD, spreading the DMA
         // pieces over both phases, or letting one wave of a pair issue all of them: all within 0.7 %,
         // the swap -8 % with 28 spilled registers -- profiles/r02_decoder_ablation.txt)
@@ -724,9 +506,6 @@ __global__ __launch_bounds__(512) void occ_decode8_kernel(
     next_chunk(t_begin, t_end);
   }
   if ((amax16 & 0xffffu) >= 0x7bffu || (amax16 >> 16) >= 0x7bffu) atomicOr(status, 2u);
-#if DEC8_BF16C || DEC8_JUNK
-  asm volatile("" ::"v"(junk[0]), "v"(junk[1]));
-#endif
   if (claim) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last tile's unused ring prefetch has landed
     if (tid() == 0) {
@@ -784,6 +563,37 @@ RFD_API int rfd_occ_pack_weights_w8(const float *fc0_w, const float *fc1_w, cons
   return 0;
 }
 
+// Launch shape of the eight-wave decoder.  The default -- persistent grid, one workgroup per CU, tiles claimed at run
+// time -- is what ships; the other shapes are the A/B controls the tests and profiles/r04_*.txt compare it with
+// (bit-identical results, all measured slower): static_partition = rounds 1-3's tiles_per_wg consecutive tiles per
+// workgroup; cus = n: a persistent grid of n < num_cu workgroups; chunk_cap = c (1..255): NOT persistent, one
+// workgroup per chunk of at most c tiles.  Initialised ONCE from RFD_DECODER_STATIC / RFD_DECODER_CUS /
+// RFD_DECODER_CHUNK (no getenv on the launch path), changed at run time through rfd_occ_set_launch_shape.
+namespace {
+struct LaunchShape {
+  std::atomic<int> static_partition, cus, chunk_cap;
+  LaunchShape() {
+    const char *e;
+    static_partition.store((e = getenv("RFD_DECODER_STATIC")) ? (atoi(e) != 0) : 0);
+    cus.store((e = getenv("RFD_DECODER_CUS")) ? atoi(e) : 0);
+    chunk_cap.store((e = getenv("RFD_DECODER_CHUNK")) ? atoi(e) : 0);
+  }
+};
+LaunchShape &launch_shape() {
+  static LaunchShape ls;
+  return ls;
+}
+}  // namespace
+
+// Each argument: >= 0 sets, < 0 leaves unchanged.  Returns 0.
+RFD_API int rfd_occ_set_launch_shape(int static_partition, int cus, int chunk_cap) {
+  LaunchShape &ls = launch_shape();
+  if (static_partition >= 0) ls.static_partition.store(static_partition != 0);
+  if (cus >= 0) ls.cus.store(cus);
+  if (chunk_cap >= 0) ls.chunk_cap.store(chunk_cap > 255 ? 255 : chunk_cap);
+  return 0;
+}
+
 static int decode_w8(int n_tiles, const float *pts, const int *tile_prop, const int *tile_src,
                      const void *packed, const float *fc_p_w, const float *table, const float *fc_out_w,
                      float fc_out_b, float *logits, const int *lin, float *values, unsigned char *pstate,
@@ -794,22 +604,16 @@ static int decode_w8(int n_tiles, const float *pts, const int *tile_prop, const 
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   int ncu = ws->num_cu > 0 ? ws->num_cu : 256;
-  // RFD_DECODER_CUS=n: persistent grid of n workgroups (one per CU: 158 KiB of LDS each), leaving the
-  // other CUs to whatever runs on other streams.  Measured: no gain, default = all.
-  static const int cu_limit = getenv("RFD_DECODER_CUS") ? atoi(getenv("RFD_DECODER_CUS")) : 0;
+  const LaunchShape &ls = launch_shape();
+  const int cu_limit = ls.cus.load(std::memory_order_relaxed);
   if (cu_limit > 0 && cu_limit < ncu) ncu = cu_limit;
-  // RFD_DECODER_STATIC=1: rounds 1-3's static partition (A/B control of the chunk claiming above)
-  // (read per launch: tests flip it inside one process)
-  const char *static_env = getenv("RFD_DECODER_STATIC");
-  const bool static_part = static_env && atoi(static_env) != 0;
-  // RFD_DECODER_CHUNK=c (1..255): NOT persistent -- one workgroup per chunk of at most c tiles (see the kernel);
-  // 0 / unset: the persistent grid with run-time claiming
-  const char *chunk_env = getenv("RFD_DECODER_CHUNK");
-  int cap = chunk_env ? atoi(chunk_env) : RFD_OCC_DEFAULT_CHUNK;
+  const bool static_part = ls.static_partition.load(std::memory_order_relaxed) != 0;
+  int cap = ls.chunk_cap.load(std::memory_order_relaxed);
   cap = cap < 0 ? 0 : cap > 255 ? 255 : cap;
   int tiles_per_wg = ceil_div(n_tiles, ncu);
   int grid = static_part ? ceil_div(n_tiles, tiles_per_wg) : (n_tiles < ncu ? n_tiles : ncu);
-  unsigned *claim = static_part ? nullptr : rfd_claim_pair(ws);
+  // the counter pair of THIS stream (serial launches: never shared with a launch in flight)
+  unsigned *claim = static_part ? nullptr : rfd_claim_pair(ws, s);
   if (!static_part && cap > 0) {
     claim = nullptr;
     tiles_per_wg = -((ncu << 8) | cap);

@@ -2,6 +2,8 @@
 // workspace, diagnostics.  No kernels here.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <mutex>
 #include <string>
 
@@ -26,7 +28,7 @@ int rfd_get_workspace(RfdWorkspace **out) {
   if (!g_ws[dev]) {
     RfdWorkspace *w = new RfdWorkspace();
     RFD_CHECK(hipMalloc((void **)&w->fps_slots,
-                        sizeof(unsigned long long) * (size_t)FPS_RING * FPS_REGION_GRANULES));
+                        sizeof(unsigned long long) * (size_t)FPS_REGIONS * FPS_REGION_GRANULES));
     RFD_CHECK(hipMalloc((void **)&w->status, sizeof(unsigned) * RFD_STATUS_SLOTS));
     RFD_CHECK(hipMemset(w->status, 0, sizeof(unsigned) * RFD_STATUS_SLOTS));
     for (int i = 0; i < RFD_STATUS_SLOTS; ++i) w->status_owner[i].store(nullptr);
@@ -38,6 +40,14 @@ int rfd_get_workspace(RfdWorkspace **out) {
     w->ring_pos.store(0);
     w->num_cu = 0;
     (void)hipDeviceGetAttribute(&w->num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    w->wall_clock_khz = 0;
+    (void)hipDeviceGetAttribute(&w->wall_clock_khz, hipDeviceAttributeWallClockRate, dev);
+    if (w->wall_clock_khz <= 0) w->wall_clock_khz = 100000;
+    // RFD_FPS_TIMEOUT_MS: read once; rfd_fps_set_timeout_ms changes it at run time (tests)
+    const char *to = getenv("RFD_FPS_TIMEOUT_MS");
+    const int to_ms = to ? atoi(to) : 0;
+    w->fps_timeout_ms.store(to_ms > 0 ? to_ms : RFD_FPS_TIMEOUT_MS_DEFAULT);
+    w->fps_force_ppt.store(0);
     g_ws[dev] = w;
   }
   *out = g_ws[dev];
@@ -46,19 +56,24 @@ int rfd_get_workspace(RfdWorkspace **out) {
 
 RFD_API const char *rfd_last_error_string(void) { return g_last_error.c_str(); }
 
-unsigned *rfd_status_word(RfdWorkspace *ws, hipStream_t stream) {
+int rfd_status_slot(RfdWorkspace *ws, hipStream_t stream) {
   void *key = (void *)stream;
-  if (!key) return ws->status;                              // the null stream shares slot 0
+  if (!key) return 0;                                       // the null stream shares slot 0
+  // Pass 1: the slot this stream already owns, wherever it is.  rfd_release_stream leaves free slots in the
+  // MIDDLE of the table; claiming the first free slot before looking at the rest moved a live stream from slot 5
+  // to a freed slot 3 -- flags raised in slot 5 by kernels still in flight were then never reported to it, and the
+  // stream held two slots.
+  for (int i = 1; i < RFD_STATUS_SLOTS; ++i)
+    if (ws->status_owner[i].load(std::memory_order_acquire) == key) return i;
+  // Pass 2: claim a free one.  (One stream is driven by one host thread at a time -- HIP's own rule for anything
+  // that orders work on it -- so two threads do not race to claim two slots for the same stream.)
   for (int i = 1; i < RFD_STATUS_SLOTS; ++i) {
-    void *cur = ws->status_owner[i].load(std::memory_order_acquire);
-    if (cur == key) return ws->status + i;
-    if (!cur) {
-      void *expected = nullptr;
-      if (ws->status_owner[i].compare_exchange_strong(expected, key, std::memory_order_acq_rel)) return ws->status + i;
-      if (expected == key) return ws->status + i;
-    }
+    void *expected = nullptr;
+    if (ws->status_owner[i].load(std::memory_order_acquire) == nullptr &&
+        ws->status_owner[i].compare_exchange_strong(expected, key, std::memory_order_acq_rel))
+      return i;
   }
-  return ws->status;                                        // more than 63 streams: the shared word
+  return 0;                                                 // more than 63 streams: the shared word
 }
 
 // Every word (all streams): synchronises the DEVICE, returns the OR of the flags and clears them.
@@ -122,6 +137,60 @@ RFD_API int rfd_release_stream(void *stream) {
     ws->status_owner[i].store(nullptr, std::memory_order_release);
     return (int)v;
   }
+  return 0;
+}
+
+// ---- multi-workgroup FPS: time-out and geometry (diagnostics / tests) ------------------------------------------
+// A launch whose G workgroups cannot all be resident (a CU-masked stream, a partitioned GPU, somebody else's
+// persistent kernel holding the CUs) can never finish its first exchange; the reference's behaviour for a launch
+// that cannot run is to fail fast (cuda_utils.h:30-39).  A workgroup that has polled `ms` for one round's
+// candidates raises the launch's sticky abort word: every workgroup -- running or started later -- leaves, status
+// bit 0 is set and the host raises.  Returns the previous value; ms <= 0 restores the default.
+RFD_API int rfd_fps_set_timeout_ms(int ms) {
+  RfdWorkspace *ws;
+  if (rfd_get_workspace(&ws)) return -1;
+  return ws->fps_timeout_ms.exchange(ms > 0 ? ms : RFD_FPS_TIMEOUT_MS_DEFAULT);
+}
+
+// Points per thread of the multi-workgroup kernel (0 = the launcher's choice).  Sweeps of the exchange geometry
+// (tools/fps_sweep.py) and the time-out tests only; the result never depends on it.  Returns the previous value,
+// -2 for a value that is not instantiated.
+RFD_API int rfd_fps_set_geometry(int points_per_thread) {
+  RfdWorkspace *ws;
+  if (rfd_get_workspace(&ws)) return -1;
+  switch (points_per_thread) {
+    case 0: case 5: case 8: case 10: case 16: case 20: case 32: case 40: case 64: break;
+    default: return -2;
+  }
+  return ws->fps_force_ppt.exchange(points_per_thread);
+}
+
+// A HIP stream confined to compute units [first_cu, first_cu + n_cus) of the current device
+// (hipExtStreamCreateWithCUMask).  Not used by the product path (partitioning the chip between the detection stage
+// and the decoder was measured and dropped: profiles/r04_cu_mask.txt); it is how the tests make a multi-workgroup
+// FPS launch that cannot be co-resident.  The caller destroys it with rfd_stream_destroy.
+RFD_API int rfd_stream_create_cu_mask(int first_cu, int n_cus, void **stream) {
+  RfdWorkspace *ws;
+  int rc = rfd_get_workspace(&ws);
+  if (rc) return rc;
+  const int ncu = ws->num_cu > 0 ? ws->num_cu : 256;
+  if (!stream || first_cu < 0 || n_cus <= 0 || first_cu + n_cus > ncu || ncu > 1024) {
+    rfd_set_error("rfd_stream_create_cu_mask: range", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  const int words = (ncu + 31) / 32;
+  uint32_t mask[32] = {0};
+  for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+  hipStream_t s;
+  RFD_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+  *stream = (void *)s;
+  return 0;
+}
+
+RFD_API int rfd_stream_destroy(void *stream) {
+  if (!stream) return 0;
+  (void)rfd_release_stream(stream);
+  RFD_CHECK(hipStreamDestroy((hipStream_t)stream));
   return 0;
 }
 

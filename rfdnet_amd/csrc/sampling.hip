@@ -12,6 +12,10 @@
 //   ->  (G > 1) all-to-all exchange of the G candidates through 8-byte
 //       {round-tag, value} granules in global memory (relaxed agent-scope
 //       atomics; the data is its own flag) -> every wave picks the winner.
+// A launch whose G workgroups are not all resident can never complete an exchange.  It does not hang: a wave
+// that has polled for longer than the launch's time-out raises the region's sticky abort word, every workgroup
+// (polling, or dispatched only later) sees it and leaves the round loop, and status bit 0 tells the host
+// (the reference's launch that cannot run fails fast too, cuda_utils.h:30-39).
 // HBM traffic is the algorithmic minimum: 12 B/point in, 4 B/point (temp) +
 // 4 B/sample out.
 //
@@ -29,9 +33,12 @@ namespace {
 
 constexpr int FPS_THREADS = 256;
 constexpr int FPS_WAVES = FPS_THREADS / 64;
-constexpr unsigned FPS_SPIN_LIMIT = 1u << 22;
+constexpr unsigned FPS_SLOW_POLLS = 256;   // polls between two looks at the clock and the abort word (a healthy round
+                                           // needs a handful of polls, so its path never pays for either)
 
 typedef unsigned long long u64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Wave-wide unsigned max with DPP (no LDS crossbar traffic): prefix max inside
 // each 16-lane row (row_shr 1,2,4,8), row 0->1 / 2->3 (row_bcast:15), then
@@ -97,7 +104,7 @@ template <int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
     int n, int m, int G, int bs_log2, int cpb, const float *__restrict__ dataset,
     float *__restrict__ temp, int *__restrict__ idxs,
-    float *__restrict__ new_xyz, u64 *slots, unsigned *status) {
+    float *__restrict__ new_xyz, u64 *region, unsigned *status, u64 timeout_ticks) {
   const int batch = blockIdx.x / G;
   const int g = blockIdx.x - batch * G;
   const int t = threadIdx.x;
@@ -106,11 +113,13 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
   temp += (size_t)batch * n;
   idxs += (size_t)batch * m;
   if (new_xyz) new_xyz += (size_t)batch * m * 3;
-  slots += (size_t)batch * G * 10;  // [g][parity][5]
+  u64 *abort_word = region;  // one per launch: any scene's time-out ends them all
+  u64 *slots = region + FPS_REGION_HEAD + (size_t)batch * G * 10;  // [g][parity][5]
 
-  __shared__ u64 s_key[2][FPS_WAVES];
-  __shared__ int s_k[2][FPS_WAVES];
-  __shared__ float s_xyz[2][FPS_WAVES][3];
+  __shared__ int s_abort;
+  // a wave's candidate: {key lo, key hi, k, x} and {y, z}; [parity][wave]
+  __shared__ __attribute__((aligned(16))) u32x4 s_a[2][FPS_WAVES];
+  __shared__ __attribute__((aligned(8))) f32x2 s_yz[2][FPS_WAVES];
 
   // ---- load this thread's points once; they stay in registers ----
   float px[PPT], py[PPT], pz[PPT], td[PPT];
@@ -123,10 +132,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
     px[i] = in ? dataset[(size_t)k * 3 + 0] : 0.f;
     py[i] = in ? dataset[(size_t)k * 3 + 1] : 0.f;
     pz[i] = in ? dataset[(size_t)k * 3 + 2] : 0.f;
-    td[i] = 1e10f;  // sampling.cpp:74-76
     const float mag = sumsq3(px[i], py[i], pz[i]);       // sampling_gpu.cu:100
     const bool skip = !in || ((double)mag <= 1e-3);      // :101 (double literal)
     nrank[i] = skip ? 0u : ~fps_rank(k, bs_log2, cpb);
+    // running min-distance, 1e10 at the start (sampling.cpp:74-76).  A skipped / absent point carries 0 instead:
+    // min(d, 0) = 0 and rank 0 make its key 0 = "no candidate" with no per-point predicate in the round loop
+    // (a real point at distance 0 still has a non-zero rank); the reference never touches a skipped point's
+    // temp, so 1e10 is what is written back for it at the end
+    td[i] = skip ? 0.f : 1e10f;
   }
   const float p0x = dataset[0], p0y = dataset[1], p0z = dataset[2];
 
@@ -135,6 +148,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
     idxs[0] = 0;
     if (new_xyz) { new_xyz[0] = p0x; new_xyz[1] = p0y; new_xyz[2] = p0z; }
   }
+  if (t == 0) s_abort = 0;  // (the first barrier of round 1 orders it)
 
   for (int j = 1; j < m; ++j) {
     const int par = j & 1;
@@ -146,9 +160,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
     for (int i = 0; i < PPT; ++i) {
       const float d = sumsq3(px[i] - cx, py[i] - cy, pz[i] - cz);  // :103-104
       const float d2 = fminf(d, td[i]);                             // :106
-      const bool ok = nrank[i] != 0u;
-      td[i] = ok ? d2 : td[i];
-      const u64 key = ok ? (((u64)__float_as_uint(d2) << 32) | nrank[i]) : 0ull;
+      td[i] = d2;
+      const u64 key = ((u64)__float_as_uint(d2) << 32) | nrank[i];
       const bool better = key > c.key;
       c.key = better ? key : c.key;
       c.k = better ? base + i * FPS_THREADS : c.k;
@@ -161,25 +174,34 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
     Cand w = wave_select(c);
     FPS_STAMP(2);
     if (lane == 0) {
-      s_key[par][wave] = w.key;
-      s_k[par][wave] = w.k;
-      s_xyz[par][wave][0] = w.x;
-      s_xyz[par][wave][1] = w.y;
-      s_xyz[par][wave][2] = w.z;
+      s_a[par][wave] = u32x4{(unsigned)w.key, (unsigned)(w.key >> 32), (unsigned)w.k, __float_as_uint(w.x)};
+      s_yz[par][wave] = f32x2{w.y, w.z};
     }
     __syncthreads();
+    // all four candidates in ONE round of broadcast reads (left to itself hipcc makes every payload read conditional
+    // on the key comparison before it: four dependent LDS round trips per round), then register selects
+    u32x4 ca[FPS_WAVES];
+    f32x2 cyz[FPS_WAVES];
+#pragma unroll
+    for (int q = 0; q < FPS_WAVES; ++q) { ca[q] = s_a[par][q]; cyz[q] = s_yz[par][q]; }
+    int gave_up = s_abort;
+#pragma unroll
+    for (int q = 0; q < FPS_WAVES; ++q) asm volatile("" : "+v"(ca[q]), "+v"(cyz[q]));
+    asm volatile("" : "+v"(gave_up));
+    // a wave of this workgroup gave up in the previous round's exchange (below): everybody leaves here, together
+    if (G > 1 && gave_up) break;
     Cand b;
-    b.key = s_key[par][0]; b.k = s_k[par][0];
-    b.x = s_xyz[par][0][0]; b.y = s_xyz[par][0][1]; b.z = s_xyz[par][0][2];
+    b.key = ((u64)ca[0].y << 32) | ca[0].x; b.k = (int)ca[0].z;
+    b.x = __uint_as_float(ca[0].w); b.y = cyz[0].x; b.z = cyz[0].y;
 #pragma unroll
     for (int q = 1; q < FPS_WAVES; ++q) {
-      const u64 kq = s_key[par][q];
+      const u64 kq = ((u64)ca[q].y << 32) | ca[q].x;
       const bool better = kq > b.key;
       b.key = better ? kq : b.key;
-      b.k = better ? s_k[par][q] : b.k;
-      b.x = better ? s_xyz[par][q][0] : b.x;
-      b.y = better ? s_xyz[par][q][1] : b.y;
-      b.z = better ? s_xyz[par][q][2] : b.z;
+      b.k = better ? (int)ca[q].z : b.k;
+      b.x = better ? __uint_as_float(ca[q].w) : b.x;
+      b.y = better ? cyz[q].x : b.y;
+      b.z = better ? cyz[q].y : b.z;
     }
     FPS_STAMP(3);
     if (G > 1) {
@@ -199,6 +221,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
       const u64 *theirs = slots + ((size_t)lane * 2 + par) * 5;
       unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
       unsigned spins = 0;
+      u64 t_first = 0;
       for (;;) {
         bool ok = true;
         if (lane < G) {
@@ -215,9 +238,21 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
           f3 = (unsigned)g3; f4 = (unsigned)g4;
         }
         if (__all(ok)) break;
-        if (++spins > FPS_SPIN_LIMIT) {  // bounded spin: flag and bail out
-          if (lane == 0) atomicOr(status, 1u);
-          break;
+        if ((++spins % FPS_SLOW_POLLS) == 0) {
+          // slow path: somebody is late.  Leave -- for good, the whole launch -- when another workgroup has
+          // already given up or this wave has waited out the time-out itself (wall clock, not a poll count: a poll
+          // takes anything from 0.3 to several us depending on what else uses the memory system).
+          const u64 now = (u64)wall_clock64();
+          if (t_first == 0) t_first = now;
+          const bool dead = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+          if (dead || now - t_first > timeout_ticks) {
+            if (lane == 0) {
+              __hip_atomic_store(abort_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              atomicOr(status, 1u);
+              s_abort = 1;
+            }
+            break;  // this round's "winner" is garbage; the flag is read behind the next round's barrier
+          }
         }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -246,7 +281,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = base + i * FPS_THREADS;
-    if (k < n) temp[k] = td[i];
+    if (k < n) temp[k] = nrank[i] ? td[i] : 1e10f;
   }
 #endif
 }
@@ -278,12 +313,12 @@ __global__ void gather_points_grad_kernel(int c, int n, int m,
 template <int PPT>
 int launch_fps(int nb, int n, int m, int G, int bs_log2, int cpb,
                const float *dataset, float *temp, int *idxs, float *new_xyz,
-               u64 *slots, unsigned *status, hipStream_t s) {
+               u64 *region, unsigned *status, u64 timeout_ticks, hipStream_t s) {
   // (packing the G exchanging workgroups onto one XCD -- launching 8x the blocks
   // and using every 8th -- was measured 15 % SLOWER than letting them spread)
   hipLaunchKernelGGL(fps_kernel<PPT>, dim3(nb * G), dim3(FPS_THREADS), 0, s, n,
-                     m, G, bs_log2, cpb, dataset, temp, idxs, new_xyz, slots,
-                     status);
+                     m, G, bs_log2, cpb, dataset, temp, idxs, new_xyz, region,
+                     status, timeout_ticks);
   RFD_CHECK_LAUNCH();
   return 0;
 }
@@ -298,38 +333,46 @@ int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
   if (rc) return rc;
   // geometry: G workgroups x 256 threads x PPT points cover n
   const int per_thread = ceil_div(n, FPS_THREADS);
+  const int forced = ws->fps_force_ppt.load(std::memory_order_relaxed);
   int ppt, G;
-  if (per_thread <= 16) {  // one workgroup holds the scene
+  if (per_thread <= 16 && !(forced && per_thread > forced)) {  // one workgroup holds the scene
     G = 1;
     ppt = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : per_thread <= 8 ? 8 : 16;
+  } else if (forced) {  // rfd_fps_set_geometry: sweeps and tests
+    ppt = forced;
+    G = ceil_div(n, FPS_THREADS * ppt);
   } else {
-    // aim at ~10 points/thread; more when the scene would need > 64 workgroups
+    // ~10 points/thread (SA1: 32 exchange units; the sweep towards fewer, fatter units is profiles/r05_fps_sweep.txt);
+    // more when the scene would need > 64 workgroups
     ppt = 10;
     G = ceil_div(n, FPS_THREADS * ppt);
     if (G > 64) { ppt = 16; G = ceil_div(n, FPS_THREADS * ppt); }
     if (G > 64) { ppt = 32; G = ceil_div(n, FPS_THREADS * ppt); }
     if (G > 64) { ppt = 64; G = ceil_div(n, FPS_THREADS * ppt); }
-    if (G > 64) { rfd_set_error("furthest_point_sampling: n > 1048576 unsupported", hipErrorInvalidValue); return (int)hipErrorInvalidValue; }
   }
+  if (G > 64) { rfd_set_error("furthest_point_sampling: n > 1048576 unsupported", hipErrorInvalidValue); return (int)hipErrorInvalidValue; }
   const int bs = ref_opt_n_threads(n);
   int bs_log2 = 0;
   while ((1 << bs_log2) < bs) ++bs_log2;
   const int cpb = ceil_div(n, bs);
   const int batches_per_launch = G > 1 ? (FPS_MAX_WG / G) : b;
+  const u64 timeout_ticks = (u64)ws->fps_timeout_ms.load(std::memory_order_relaxed) * (u64)ws->wall_clock_khz;
+  unsigned *status = rfd_status_word(ws, s);
   for (int b0 = 0; b0 < b; b0 += batches_per_launch) {
     const int nb = (b - b0) < batches_per_launch ? (b - b0) : batches_per_launch;
-    u64 *slots = nullptr;
+    u64 *region = nullptr;
     if (G > 1) {
-      slots = ws->fps_slots + (size_t)(ws->ring_pos.fetch_add(1) % FPS_RING) * FPS_REGION_GRANULES;
-      RFD_CHECK(hipMemsetAsync(slots, 0, sizeof(u64) * (size_t)nb * G * 10, s));
+      // this stream's own region (launches on a stream are serial); abort word + exchange granules zeroed per launch
+      region = rfd_fps_region(ws, s);
+      RFD_CHECK(hipMemsetAsync(region, 0, sizeof(u64) * (FPS_REGION_HEAD + (size_t)nb * G * 10), s));
     }
     const float *ds = dataset + (size_t)b0 * n * 3;
     float *tp = temp + (size_t)b0 * n;
     int *ix = idxs + (size_t)b0 * m;
     float *nx = new_xyz ? new_xyz + (size_t)b0 * m * 3 : nullptr;
     switch (ppt) {
-#define FPS_CASE(P) case P: rc = launch_fps<P>(nb, n, m, G, bs_log2, cpb, ds, tp, ix, nx, slots, rfd_status_word(ws, s), s); break;
-      FPS_CASE(1) FPS_CASE(2) FPS_CASE(4) FPS_CASE(8) FPS_CASE(10) FPS_CASE(16) FPS_CASE(32) FPS_CASE(64)
+#define FPS_CASE(P) case P: rc = launch_fps<P>(nb, n, m, G, bs_log2, cpb, ds, tp, ix, nx, region, status, timeout_ticks, s); break;
+      FPS_CASE(1) FPS_CASE(2) FPS_CASE(4) FPS_CASE(5) FPS_CASE(8) FPS_CASE(10) FPS_CASE(16) FPS_CASE(20) FPS_CASE(32) FPS_CASE(40) FPS_CASE(64)
 #undef FPS_CASE
       default: rc = (int)hipErrorInvalidValue;
     }

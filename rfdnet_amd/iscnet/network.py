@@ -171,6 +171,9 @@ class ISCNet(nn.Module):
         hook(codes, cls): called before the completion (the benchmark installs its copy scheduling there)."""
         from .. import _lib, gemm
         for attempt in (0, 1):
+            # the GEMM scale THIS attempt runs at: the model (and gemm.SA) is shared by every scene in flight, so
+            # another scene may lower it while this one runs (ADVICE round 4)
+            sa_used = gemm.SA
             codes = self.object_codes(end_points, proposal_features, ids, pc)
             cls = self.cls_codes(end_points, ids)
             # A snapshot of the stream's status word is taken HERE, before the completion, without waiting: a GEMM that
@@ -184,9 +187,15 @@ class ISCNet(nn.Module):
             try:
                 return self.complete(codes, cls, pc.device, return_grids=return_grids, before=snap)
             except _StageFlag as e:
-                if e.status & 4 and not e.status & ~4 and attempt == 0 and gemm.lower_scale():
-                    continue                               # the stage again at the fallback GEMM scale
-                _lib.raise_status(e.status)                # FPS exchange time-out, or an overflow at the fallback scale
+                if e.status & 4 and not e.status & ~4 and attempt == 0:
+                    with _lib.BUILD_LOCK:
+                        lowered = gemm.lower_scale()
+                    # again when the scale came down -- by this scene, or by another scene in flight since this one
+                    # started (its run was at the OLD scale: lower_scale() says "already at the fallback" but THIS
+                    # scene has never run there); only a flag raised AT the fallback scale is a real overflow
+                    if lowered or gemm.SA < sa_used:
+                        continue
+                _lib.raise_status(e.status)                # FPS abort, or an overflow at the fallback scale
                 raise
 
     def complete(self, codes, cls, device, return_grids=False, before=None):
@@ -201,16 +210,21 @@ class ISCNet(nn.Module):
         account."""
         from .. import _lib
         gen = self.completion.generator
+        dec = self.completion.decoder
         run = gen.generate_grids if return_grids else gen.generate_mesh
+        ka_used = dec.ka                     # the decoder is shared by the scenes in flight: see reconstruct()
         out = run(codes, cls)
         with torch.cuda.device(device):
             st = _lib.stream_status_bits()
         if before is not None and before.read():
             raise _StageFlag(before.read())
-        if st & 2 and self.completion.decoder.lower_activation_scale():
-            out = run(codes, cls)
-            with torch.cuda.device(device):
-                st = (st & ~2) | _lib.stream_status_bits()
+        if st & 2:
+            with _lib.BUILD_LOCK:
+                lowered = dec.lower_activation_scale()
+            if lowered or dec.ka < ka_used:  # this run was folded at a scale that has come down since: once more
+                out = run(codes, cls)
+                with torch.cuda.device(device):
+                    st = (st & ~2) | _lib.stream_status_bits()
         _lib.raise_status(st)
         return out
 

@@ -213,6 +213,7 @@ class DecoderCBatchNorm(nn.Module):
         B, T, _ = p.shape
         if c.dim() == 3:
             c = c.squeeze(2)
+        ka_used = self.ka                  # (a decoder shared by several host threads may be lowered by another one)
         table, fc_p_w = self.fold(z.float(), c.float())
         tpad = (T + TILE - 1) // TILE * TILE
         if tpad != T:
@@ -228,7 +229,10 @@ class DecoderCBatchNorm(nn.Module):
             # an overflow at the default scale is answered by the fallback scale, not by an exception
             with torch.cuda.device(p.device):
                 st = _lib.stream_status_bits()
-            if st & 2 and self.lower_activation_scale():
+            if st & 2:
+                with _lib.BUILD_LOCK:
+                    lowered = self.lower_activation_scale()
+            if st & 2 and (lowered or self.ka < ka_used):
                 table, fc_p_w = self.fold(z.float(), c.float())
                 logits = self.decode_tiles(pp.reshape(-1, 3), tile_prop, table, fc_p_w)
                 with torch.cuda.device(p.device):

@@ -196,38 +196,55 @@ def _ragged_launch(dec, K=37, seed=3, skip_every=0):
 
 def test_claimed_chunks_and_static_partition_give_identical_logits(hip):
     """The eight-wave kernel hands its tiles out at run time (chunk_range, csrc/occ_decoder8.hip); who computes a tile
-    must not matter: bit-identical to rounds 1-3's static partition (RFD_DECODER_STATIC=1), run after run, with skipped
-    tiles, through the fused MISE scatter, and on a reduced grid (RFD_DECODER_CUS).  The counter pair of a launch is
-    reset by the kernel itself: more launches than the pool has slots, then the comparison again."""
+    must not matter: bit-identical to rounds 1-3's static partition (rfd_occ_set_launch_shape), run after run, with skipped
+    tiles, through the fused MISE scatter, one workgroup per chunk, and on a reduced grid.  The counter pair of a
+    launch (its stream's own, or -- on the null stream -- one of the shared pool) is reset by the kernel itself: 1100
+    launches in a row, on a stream of its own and on the null stream, then the comparison again."""
     dec = seeded_decoder(11)
     assert dec.kernel == "w8"
     for skip in (0, 7):
         pts, tile_prop, table, fcp = _ragged_launch(dec, skip_every=skip)
         keep = (tile_prop >= 0).repeat_interleave(128)
         with torch.no_grad():
-            os.environ["RFD_DECODER_STATIC"] = "1"
+            lib = hip.lib()
+            lib.rfd_occ_set_launch_shape(1, -1, -1)
             try:
                 ref = dec.decode_tiles(pts, tile_prop, table, fcp)
             finally:
-                del os.environ["RFD_DECODER_STATIC"]
+                lib.rfd_occ_set_launch_shape(0, -1, -1)
             runs = [dec.decode_tiles(pts, tile_prop, table, fcp) for _ in range(3)]
-            for cap in ("0", "1", "5", "16", "255"):       # persistent + claiming / one workgroup per chunk of <= cap tiles
-                os.environ["RFD_DECODER_CHUNK"] = cap
+            for cap in (0, 1, 5, 16, 255):       # persistent + claiming / one workgroup per chunk of <= cap tiles
+                lib.rfd_occ_set_launch_shape(-1, -1, cap)
                 try:
                     runs.append(dec.decode_tiles(pts, tile_prop, table, fcp))
                 finally:
-                    del os.environ["RFD_DECODER_CHUNK"]
+                    lib.rfd_occ_set_launch_shape(-1, -1, 0)
+            for cus in (200, 37):                # a reduced persistent grid
+                lib.rfd_occ_set_launch_shape(-1, cus, -1)
+                try:
+                    runs.append(dec.decode_tiles(pts, tile_prop, table, fcp))
+                finally:
+                    lib.rfd_occ_set_launch_shape(-1, 0, -1)
         hip.device_status()
         for r in runs:
             assert torch.equal(r[keep], ref[keep])
-    # the pool of counter pairs (1024 slots) wraps: every slot must come back zeroed
+    # the shared pool of counter pairs (null stream: 960 slots) wraps, a stream's own pair is used 1100 times in a
+    # row: every pair must come back zeroed
     small = tile_prop[:3].contiguous()
     with torch.no_grad():
         for _ in range(1100):
             dec.decode_tiles(pts[:3 * 128], small, table, fcp)
         again = dec.decode_tiles(pts, tile_prop, table, fcp)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(1100):
+                dec.decode_tiles(pts[:3 * 128], small, table, fcp)
+            again2 = dec.decode_tiles(pts, tile_prop, table, fcp)
+        side.synchronize()
     hip.device_status()
     assert torch.equal(again[keep], ref[keep])
+    assert torch.equal(again2[keep], ref[keep])
 
 
 def test_claimed_chunks_through_the_fused_scatter(hip):
@@ -247,13 +264,12 @@ def test_claimed_chunks_through_the_fused_scatter(hip):
     for static in (True, False):
         values = torch.full((K, n_per), float("nan"), device="cuda")
         pstate = torch.ones(K, n_per, dtype=torch.uint8, device="cuda")
-        if static:
-            os.environ["RFD_DECODER_STATIC"] = "1"
+        hip.lib().rfd_occ_set_launch_shape(int(static), -1, -1)
         try:
             with torch.no_grad():
                 dec.decode_tiles(pts, tile_prop, table, fcp, scatter=(lin, values, pstate))
         finally:
-            os.environ.pop("RFD_DECODER_STATIC", None)
+            hip.lib().rfd_occ_set_launch_shape(0, -1, -1)
         hip.device_status()
         outs.append((values, pstate))
     assert torch.equal(outs[0][1], outs[1][1])

@@ -236,6 +236,64 @@ def test_default_stream_flags_stay_with_the_default_stream_and_slots_are_recycle
     hip.device_status()
 
 
+def test_a_stream_keeps_its_status_slot_when_a_lower_slot_is_released(hip):
+    """rfd_release_stream leaves free slots in the middle of the table; a live stream that owns a
+    HIGHER slot must keep it at its next launch (round 4 claimed the first free slot before it reached the one the
+    stream already owned: flags raised by kernels in flight in the old slot were never reported to that stream, and the
+    stream then held two slots)."""
+    from rfdnet_amd import _lib, gemm
+    w = torch.randn(128, 32, device="cuda") * 0.1
+    bad = torch.zeros(128, 32, device="cuda")
+    bad[3, 5] = 5000.0
+    good = torch.zeros(128, 32, device="cuda")
+    torch.cuda.synchronize()
+    low, high = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(low):
+        gemm.linear(good, w)                              # claims the lower slot
+    with torch.cuda.stream(high):
+        gemm.linear(bad, w)                               # claims the next one and raises bit 2 in it
+    _lib.release_stream(low)                              # a hole below `high`'s slot
+    with torch.cuda.stream(high):
+        gemm.linear(good, w)                              # must NOT move `high` into the hole ...
+        assert _lib.stream_status_bits() == 4             # ... its pending flag is still its own
+        assert _lib.stream_status_bits() == 0
+    filler = torch.cuda.Stream()
+    with torch.cuda.stream(filler):
+        gemm.linear(bad, w)                               # takes the hole; `high` does not see this flag
+    with torch.cuda.stream(high):
+        gemm.linear(good, w)
+        assert _lib.stream_status_bits() == 0
+    with torch.cuda.stream(filler):
+        assert _lib.stream_status_bits() == 4
+    for s in (high, filler):
+        _lib.release_stream(s)
+    hip.device_status()
+
+
+def test_two_status_snapshots_on_one_stream_do_not_overwrite_each_other(hip):
+    """a caller that snapshots per stage takes a second snapshot before it has read the first; each
+    must keep its own flags, and read() needs no synchronisation by the caller."""
+    from rfdnet_amd import _lib, gemm
+    w = torch.randn(128, 32, device="cuda") * 0.1
+    bad = torch.zeros(128, 32, device="cuda")
+    bad[3, 5] = 5000.0
+    good = torch.zeros(128, 32, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        gemm.linear(bad, w)
+        first = _lib.StatusSnapshot()
+        gemm.linear(good, w)
+        second = _lib.StatusSnapshot()
+        gemm.linear(bad, w)
+        third = _lib.StatusSnapshot()
+        assert (first.read(), second.read(), third.read()) == (4, 0, 4)
+        assert first.read() == 4                          # reading twice is fine
+        assert _lib.stream_status_bits() == 0             # every snapshot reset the word behind it
+    _lib.release_stream(s)
+    hip.device_status()
+
+
 def test_pool_only_launch_is_range_checked_too(hip):
     """store=False launches feed the pooled maximum to the next split GEMM: the range watch covers them as well
     (round-2 advisory: `if (g.C && ...)` skipped them)."""

@@ -198,3 +198,54 @@ def test_worker_view_shares_every_weight_but_not_the_generator_state():
     g1.round_hook = lambda r, d: None
     assert g0.stats == {} and g0.round_hook is None
     assert net._modules['completion'] is net.completion and net.completion.generator is g0
+
+
+def test_a_scene_flagged_at_the_old_scale_reruns_when_another_scene_lowered_the_shared_decoder(monkeypatch):
+    """every scene in flight shares ONE decoder (worker_view), so its activation scale may be lowered by
+    scene A while scene B -- folded at the old scale -- is still running.  B's range flag must then be answered by a
+    re-run at the fallback scale, although lower_activation_scale() says "already there"; only a flag raised by a run
+    that itself used the fallback scale is a real overflow and raises.  (CPU: the status word and the runs are stubs.)"""
+    import types
+    import pytest
+    from rfdnet_amd import _lib
+    from rfdnet_amd.iscnet.network import ISCNet
+
+    class Dec(object):
+        ka = 6
+
+        def lower_activation_scale(self):
+            if self.ka <= 3:
+                return False
+            self.ka = 3
+            return True
+
+    def make(statuses, other_scene_lowers):
+        dec, runs = Dec(), []
+
+        def run(codes, cls):
+            runs.append(dec.ka)
+            if other_scene_lowers and len(runs) == 1:
+                dec.ka = 3                      # scene A, on another host thread, answers ITS flag meanwhile
+            return "meshes@%d" % runs[-1]
+        gen = types.SimpleNamespace(generate_mesh=run, generate_grids=run)
+        net = types.SimpleNamespace(completion=types.SimpleNamespace(generator=gen, decoder=dec))
+        seq = list(statuses)
+        monkeypatch.setattr(_lib, "stream_status_bits", lambda: seq.pop(0))
+        import contextlib
+        import torch
+        monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())    # no GPU in this tier
+        return net, runs
+
+    net, runs = make([2, 0], other_scene_lowers=True)
+    assert ISCNet.complete(net, None, None, None) == "meshes@3" and runs == [6, 3]
+    net, runs = make([2, 0], other_scene_lowers=False)          # the ordinary case: this scene lowers the scale itself
+    assert ISCNet.complete(net, None, None, None) == "meshes@3" and runs == [6, 3]
+    net, runs = make([2], other_scene_lowers=False)
+    net.completion.decoder.ka = 3                               # flagged AT the fallback scale: a real overflow
+    with pytest.raises(_lib.RfdHipError, match="occupancy decoder"):
+        ISCNet.complete(net, None, None, None)
+    assert runs == [3]
+    net, runs = make([2, 2], other_scene_lowers=True)           # still flagged after the re-run: raises
+    with pytest.raises(_lib.RfdHipError, match="occupancy decoder"):
+        ISCNet.complete(net, None, None, None)
+    assert runs == [6, 3]
