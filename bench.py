@@ -21,7 +21,15 @@ raises is counted as failed, the run goes on.  Prints ONE JSON line on rank 0.
   headline (default)  configs[1]: 80 000 points, 256 proposals, 64^3 MISE
   mise128             configs[4] per GPU: 128^3 MISE (resolution_0 32, upsampling_steps 2)
   dense32             configs[0]: 40 000 points (sampled WITH replacement), dense 32^3 grid
-  stress              configs[2]: decoder only, 256 proposals x 262 144 query points
+  stress              configs[2]: decoder only, 256 proposals x 262 144 query points (f16x3 timed; the single-pass f16
+                      mode and the matrix-pipe-busy counter ride in `roofline`)
+  demo                NOT a BASELINE config: the reference's `main.py --mode demo` workload (demo.py:200-276, ISCNet_test.yaml):
+                      80 000 points, proposals selected by objectness + 3-D NMS (about a dozen survive), dense 32^3 grids
+
+--scenes N   sweep N scenes in the timed region (scene i -> rank i mod world), e.g. `--config mise128 --scenes 311` =
+             BASELINE configs[4] (the 311 scans of datasets/splits/fullscan/scannetv2_test.json) in one command
+--preflight  check the job before anything is built: rank count vs visible devices, a collective all-gather, the NUMA /
+             affinity / hardware-queue settings of every rank; one actionable line and a non-zero exit within 60 s
 """
 import argparse
 import json
@@ -58,7 +66,12 @@ CONFIGS = {
                          "scan, 256 proposals, dense %(resolution0)d^3 occupancy grid, meshes to host"),
     "stress": dict(points=0, resolution0=0, upsampling_steps=0, raw=0,
                    name="configs[2]: occupancy decoder stress, 256 proposals x 262 144 query points"),
+    "demo": dict(points=80000, resolution0=32, upsampling_steps=0, raw=120000, selection="nms",
+                 name="the reference's demo workload (main.py --mode demo; NOT a BASELINE config): %(points)d points, "
+                      "proposals kept by objectness > 0.5 + class-aware 3-D NMS (demo.py:223-234), dense "
+                      "%(resolution0)d^3 occupancy grids (ISCNet_test.yaml:61-63), meshes to host"),
 }
+MFMA_BUSY_FILE = os.path.join(ROOT, "profiles", "decoder_mfma_busy.json")
 
 
 def parse(argv=None):
@@ -91,14 +104,31 @@ def parse(argv=None):
                          "behind (0 = the first, longest launch; -1 = at once, when the meshes are complete)")
     ap.add_argument("--mode", choices=["f16x3", "f16x1"], default="f16x3",
                     help="decoder arithmetic; f16x3 is the parity mode (1e-4 on logits)")
+    ap.add_argument("--scenes", type=int, default=None,
+                    help="sweep: this many scenes in the timed region over the whole job (scene i -> rank i mod world); "
+                         "--steps is then derived (ceil(scenes / scenes per step)) and only reported")
+    ap.add_argument("--preflight", action="store_true",
+                    help="check ranks / devices / collective / affinity and exit (0 = the job can start)")
+    ap.add_argument("--demo-keep", type=int, default=16,
+                    help="--config demo: the objectness bias of the seeded head is shifted so that this many of scene "
+                         "0's 256 proposals pass the 0.5 threshold (NMS and empty-box removal then thin them out)")
+    ap.add_argument("--graph-detect", action="store_true",
+                    help="--config demo: replay the detection stage (backbone, voting, proposals) from a captured HIP "
+                         "graph per worker instead of ~150 launches per scene")
     args = ap.parse_args(argv)
     c = CONFIGS[args.config]
     for k in ("points", "resolution0", "upsampling_steps"):
         if getattr(args, k) is None:
             setattr(args, k, c[k])
     args.raw = c["raw"]
+    args.selection = c.get("selection", "all")
     if args.config == "stress":
         args.in_flight = 1
+    if args.scenes is not None:
+        if args.scenes <= 0 or args.config == "stress":
+            ap.error("--scenes needs a positive count and a scene configuration")
+        per_step = max(1, args.in_flight) * max(1, args.batch) * max(1, args.gpus)
+        args.steps = -(-args.scenes // per_step)
     return args
 
 
@@ -232,6 +262,7 @@ class HipBackend(object):
         # generator state (round 3 built a full replica per worker)
         self.net = self._build_net()
         self.nets = [self.net] + [self.net.worker_view() for _ in range(self.S - 1)]
+        self.graphs = [None] * self.S           # --graph-detect: (graph, static input, static outputs) per worker
         self.timers = [DecodeTimer(self.net.completion.decoder)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.S)]
         self.sinks = [MeshSink(self.device) for _ in range(self.S)]
@@ -244,6 +275,9 @@ class HipBackend(object):
             pc = synthetic.synthetic_scene(seed=10 + i, n_points=args.points, n_raw=args.raw)
             self.scenes[i] = torch.from_numpy(pc).to(self.device)
         torch.cuda.synchronize()
+        self.demo_calibration = None
+        if args.selection == "nms":
+            self.demo_calibration = self.calibrate_objectness(args.demo_keep)
         # (the lazily built caches of the SHARED model -- packed weight streams, folded BatchNorms -- are built under
         # _lib.BUILD_LOCK and published before they are stored, so the workers may start together.  A priming scene run
         # from THIS thread was tried instead and cost 8 % scenes/s for the rest of the process: profiles/r04_numa_prime.txt)
@@ -260,7 +294,35 @@ class HipBackend(object):
         synthetic.load_seeded(net, seed=10)           # the reference's seed (ISCNet_test.yaml:5)
         net = net.to(self.device).eval()
         net.completion.decoder.mode = occ_decoder.MODE_F16X3 if a.mode == "f16x3" else occ_decoder.MODE_F16X1
+        self.placeholder_sizes = bool(getattr(cfg.dataset_config, "placeholder_sizes", False))
+        if a.selection == "nms" and self.placeholder_sizes:
+            # no datasets/scannet/scannet_means.npz on the box: the synthetic run opts in (flagged in `config`)
+            cfg.eval_overrides = dict(cfg.eval_overrides or {}, allow_placeholder_sizes=True)
         return net
+
+    def calibrate_objectness(self, keep):
+        """--config demo: with seeded random weights the objectness head is noise around zero, so the reference's
+        selection (probability > dump_threshold, then NMS) would keep ~half of the 256 proposals or none.  Shift the
+        bias of the `object` logit so that exactly `keep` proposals of scene 0 pass the threshold -- a trained head
+        keeps about that many (the reference's demo output holds 13 meshes) -- and let empty-box removal and the
+        class-aware NMS thin them out as they do there.  Returns the shift (reported in `config`)."""
+        import warnings
+        torch = self.torch
+        pc = self.scenes[min(self.scenes)][None]
+        with torch.no_grad():
+            end_points, _ = self.net.detect(pc)
+            d = (end_points['objectness_scores'][0, :, 1] - end_points['objectness_scores'][0, :, 0]).double()
+            d, _ = torch.sort(d, descending=True)
+            keep = max(1, min(int(keep), d.numel() - 1))
+            thr = self.net.cfg.config['generation']['dump_threshold']
+            logit_thr = float(torch.log(torch.tensor(thr / (1.0 - thr), dtype=torch.float64)))
+            shift = logit_thr - float(d[keep - 1] + d[keep]) / 2.0
+            self.net.detection.conv3.bias[1] += shift
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")          # the placeholder-size warning: said once in `config`
+                ids = self.net.select_proposals(self.net.detect(pc)[0], 'nms', pc)
+        self.torch.cuda.synchronize()
+        return shift, int(ids.shape[1])
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -282,14 +344,24 @@ class HipBackend(object):
         torch = self.torch
         net, sink = self.nets[w], self.sinks[w]
         pc = torch.stack([self.scenes[i % self.pool] for i in ids])
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.record_scenes else None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.record_scenes else None
         if ev:
             ev[0].record()
         with torch.no_grad():
-            end_points, proposal_features = net.detect(pc)
-            sel = net.select_proposals(end_points, 'all', pc)
+            end_points, proposal_features = self.detect(w, net, pc)
+            if ev:
+                ev[4].record()
+            sel = net.select_proposals(end_points, self.args.selection, pc)
             if ev:
                 ev[1].record()
+            if sel.shape[1] == 0:                   # nothing survived the selection (ISCNet.generate returns [] too)
+                sink.start_pending()
+                if ev:
+                    ev[2].record()
+                    ev[3].record()
+                    self.scene_records.append({"scenes": [int(i) for i in ids], "worker": w, "events": ev, "queries": 0,
+                                               "rounds": 0, "meshes": 0, "vertices": 0, "triangles": 0, "failed": False})
+                return 0, 0, 0, 0
             gen = net.completion.generator
             # the previous scene's PCIe copy rides behind one decode launch (--blit-round; default the first, longest)
             tm, blit_round = self.timers[0], self.args.blit_round
@@ -321,6 +393,37 @@ class HipBackend(object):
                                        "failed": False})
         return len(meshes), int(v.shape[0]), int(f.shape[0]), gen.stats.get('n_queries', 0)
 
+    def detect(self, w, net, pc):
+        """net.detect(pc); with --graph-detect the stage is captured ONCE per worker (on its own stream, after the
+        warm-up pass has built every lazily packed weight) and replayed from a HIP graph: one launch instead of the
+        ~150 of backbone + voting + proposal head (4 x [FPS, ball query, fused SA], 2 x [three_nn, interpolate, MLP],
+        the vote and proposal heads)."""
+        if not self.args.graph_detect or pc.shape[0] != 1:
+            return net.detect(pc)
+        torch = self.torch
+        g = self.graphs[w]
+        if g is None:
+            self.graphs[w] = g = {"calls": 0}
+        g["calls"] += 1
+        if "graph" not in g:
+            if g["calls"] < 2 or "error" in g:        # first pass of this worker: eager (builds the caches)
+                return net.detect(pc)
+            try:
+                static_in = pc.clone()
+                graph = torch.cuda.CUDAGraph()
+                torch.cuda.current_stream().synchronize()
+                with torch.cuda.graph(graph, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                    out = net.detect(static_in)
+                g.update(graph=graph, static_in=static_in, out=out)
+            except Exception as e:                    # not capturable on this stack: say so, stay eager
+                g["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+                sys.stderr.write("[graph-detect] capture failed, staying eager: %s\n" % g["error"])
+                return net.detect(pc)
+        g["static_in"].copy_(pc)
+        g["graph"].replay()
+        end_points, feats = g["out"]
+        return dict(end_points), feats
+
     def scene_stats(self):
         """per-scene records of the timed region with the event times resolved (call after the final sync)"""
         out = []
@@ -329,7 +432,8 @@ class HipBackend(object):
                 out.append(r)
                 continue
             e = r.pop("events")
-            r["ms"] = {"backbone_voting_proposal": e[0].elapsed_time(e[1]), "skip_propagation": e[1].elapsed_time(e[2]),
+            r["ms"] = {"backbone_voting_proposal": e[0].elapsed_time(e[4]), "proposal_selection": e[4].elapsed_time(e[1]),
+                       "skip_propagation": e[1].elapsed_time(e[2]),
                        "completion_mise_decoder_marching_cubes": e[2].elapsed_time(e[3]), "total": e[0].elapsed_time(e[3])}
             out.append(r)
         return out
@@ -366,7 +470,7 @@ class HipBackend(object):
                 tm.records = []
         if on:
             self.round_points = {}
-        self.record_scenes = bool(on and getattr(self.args, "stats_out", None))
+        self.record_scenes = bool(on and (getattr(self.args, "stats_out", None) or self.args.selection == "nms"))
         if on:
             self.scene_records = []
 
@@ -547,6 +651,47 @@ class StressBackend(HipBackend):
                 self.dec.decode_tiles(self.pts, self.tile_prop, self.table, self.fc_p_w)
         return self.K * len(ids), 0, 0, self.K * self.T * len(ids)
 
+    def final_check(self):
+        self._lib.device_status()
+        self.selfcheck = self.decoder_selfcheck(self.dec)
+        self.alone = None
+        self.modes = self.compare_modes()
+
+    def compare_modes(self):
+        """configs[2] names "bf16 MFMA MLP": the single-pass 16-bit mode of the same kernel (occ_decode8_kernel<1>: one
+        f16 MFMA per product instead of three on (hi, lo) splits; f16 carries 3 more significand bits than bf16 at the
+        same matrix-core rate, so it bounds what a bf16 build could deliver in accuracy from above and equals it in
+        speed) next to the parity mode, on the SAME launch: both timed back to back after the timed region (HIP events on
+        the launch stream, 3 launches each after one warm-up), and their logits compared point by point."""
+        torch = self.torch
+        from rfdnet_amd.iscnet import occ_decoder
+        orig = self.timers[0]._orig
+        out = {}
+        logits = {}
+        with torch.no_grad():
+            for name, mode in (("f16x3", occ_decoder.MODE_F16X3), ("f16x1", occ_decoder.MODE_F16X1)):
+                logits[name] = orig(self.pts, self.tile_prop, self.table, self.fc_p_w, mode=mode)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    orig(self.pts, self.tile_prop, self.table, self.fc_p_w, mode=mode)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / 3
+                tf = self.K * self.T * FLOP_PER_QUERY / (ms * 1e-3) / 1e12
+                out[name] = {"kernel": "occ_decode8_kernel<%d>" % mode, "avg_launch_ms": ms, "achieved": tf,
+                             "frac": tf / MFMA_PEAK_TFLOPS, "points_per_s": self.K * self.T / (ms * 1e-3)}
+            st = self._lib.stream_status_bits()
+            d = (logits["f16x1"] - logits["f16x3"]).abs()
+            out["f16x1"].update({
+                "max_abs_dlogit_vs_f16x3": float(d.max()), "mean_abs_dlogit_vs_f16x3": float(d.mean()),
+                "sign_agreement_vs_f16x3": float(((logits["f16x1"] >= 0) == (logits["f16x3"] >= 0)).double().mean()),
+                "points_compared": int(d.numel()), "status_bits": int(st),
+                "note": "throughput mode, NOT parity (north_star: 1e-4 on logits); one 16-bit MFMA per product, f32 "
+                        "accumulate; sign = inside / outside at the 0.5 occupancy threshold"})
+        return out
+
     def kernel_name(self):
         return "%s<%d>" % ("occ_decode8_kernel" if self.dec.kernel == "w8" else "occ_decode_kernel",
                            3 if self.args.mode == "f16x3" else 1)
@@ -646,6 +791,12 @@ def run_job(args, be, rank, world, dist):
     be.sync()
     be.set_timing(True)
     plan = shard(args.warmup, args.steps)
+    if getattr(args, "scenes", None):
+        # a sweep of exactly N scenes: global scene j of the timed region (id = warm-up scenes + j) -> rank j mod world,
+        # the partition of sharding.scene_ids_for_rank (tests/test_bench_launcher.py: 311 scans -> 39 x 7 + 38)
+        first = args.warmup * per_step
+        mine = [first + j for j in sharding.scene_ids_for_rank(args.scenes, rank, world)]
+        plan = [sharding.scene_ids_for_worker(mine, w, S, NB) for w in range(S)]
     t0 = time.perf_counter()
     res = list(pool.map(lambda w: worker(w, plan[w]), range(S)))
     be.sync()
@@ -654,11 +805,12 @@ def run_job(args, be, rank, world, dist):
     be.sync()
     elapsed = time.perf_counter() - t0
     dec_ms, dec_pts, dec_launches = be.decode_totals()
-    if getattr(args, "stats_out", None) and hasattr(be, "scene_stats"):
+    be.last_scene_stats = be.scene_stats() if (getattr(be, "record_scenes", False) and hasattr(be, "scene_stats")) else None
+    if getattr(args, "stats_out", None) and be.last_scene_stats is not None:
         path = args.stats_out if rank == 0 else "%s.rank%d" % (args.stats_out, rank)
         with open(path, "w") as fh:
             json.dump({"rank": rank, "world": world, "config": args.config, "timed_region_s": elapsed,
-                       "scenes": be.scene_stats()}, fh, indent=1)
+                       "scenes": be.last_scene_stats}, fh, indent=1)
     be.set_timing(False)
     be.final_check()
     n_meshes, nv, nt, nq = (sum(r[0][i] for r in res) for i in range(4))
@@ -670,10 +822,14 @@ def run_job(args, be, rank, world, dist):
         L = 3
         worker(0, [[0]])
         be.sync()
+        be.record_scenes, be.scene_records = True, []
         t1 = time.perf_counter()
         worker(0, [[i * world] for i in range(L)])
         be.sync()
         single = (time.perf_counter() - t1) / L
+        recs = [r for r in be.scene_stats() if not r.get("failed") and "ms" in r]
+        be.record_scenes = False
+        be.single_stage_ms = {k: sum(r["ms"][k] for r in recs) / len(recs) for k in sorted(recs[0]["ms"])} if recs else None
     stats = sharding.pack_stats(steps=n_scenes - failed, elapsed_s=elapsed, n_meshes=n_meshes, n_vertices=nv,
                                 n_triangles=nt, n_queries=nq, decode_ms=dec_ms, decode_points=dec_pts,
                                 decode_launches=dec_launches, failed=failed)
@@ -785,6 +941,18 @@ def pointop_rooflines(device, pc):
     return fps, bq
 
 
+def mfma_busy(mode):
+    """matrix-pipe busy share of the decoder's SIMD time from the committed counter passes (rocprofv3 --pmc
+    SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAVE_CYCLES over tools/dec_only.py; counters cannot be read from inside this
+    process) -> (fraction or None, source)."""
+    try:
+        with open(MFMA_BUSY_FILE) as f:
+            d = json.load(f)
+        return d.get(mode, {}).get("mfma_busy"), d.get("source")
+    except (OSError, ValueError):
+        return None, None
+
+
 def traffic_per_query():
     """HBM bytes per query point of the decoder from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this benchmark; counters cannot be read from
@@ -809,6 +977,18 @@ def main(argv=None):
                  "and let bench.py spawn its own ranks)" % (args.gpus, world, args.gpus))
     cls = StubBackend if os.environ.get("RFD_BENCH_STUB") == "1" else \
         StressBackend if args.config == "stress" else HipBackend
+    if args.preflight:
+        if cls is not StubBackend and os.environ.get("RFD_PIN_NUMA", "1") != "0" and not os.environ.get("RFD_BENCH_ONE_DEVICE"):
+            cpus = sharding.pin_cpus_for_rank(local_rank)
+            if cpus:
+                sharding._pin(cpus)                     # report the affinity the job itself would run with
+        g = sharding.preflight(rank, local_rank, world, stub=cls is StubBackend,
+                               one_device=os.environ.get("RFD_BENCH_ONE_DEVICE") == "1")
+        if rank == 0:
+            print(json.dumps({"preflight": "ok", "n_gpus": world,
+                              "ranks": [dict(zip(sharding.PREFLIGHT_FIELDS, [float(x) for x in row])) for row in g]}))
+            sys.stdout.flush()
+        return
     all_cpus = None
     if cls is not StubBackend and os.environ.get("RFD_PIN_NUMA", "1") != "0" and not os.environ.get("RFD_BENCH_ONE_DEVICE"):
         # host threads, pinned mesh buffers (first touch) and the HIP runtime's helper threads on the CPUs of THIS GPU's
@@ -819,6 +999,15 @@ def main(argv=None):
             all_cpus = os.sched_getaffinity(0)
             sharding._pin(cpus)
     be = cls(args, rank, local_rank, world)
+    if all_cpus and cls is not StubBackend:
+        # the pinning above was chosen BEFORE the runtime came up, from the KFD topology; now HIP says which PCI device
+        # this rank really drives: if its NUMA node is another one, re-pin (threads created from here on follow)
+        want = sharding.numa_cpus_for_bdf(sharding.device_bdf(be.torch.cuda.get_device_properties(be.device)) or "")
+        if want and not set(os.sched_getaffinity(0)) <= set(want):
+            want = sorted(set(want) & set(all_cpus))
+            if want:
+                sys.stderr.write("[rank %d] re-pinning to the NUMA node of the GPU's PCI address (%d CPUs)\n" % (rank, len(want)))
+                sharding._pin(want)
     dist = None
     # RFD_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL barrier /
     # all-gather on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 1 bench.py`)
@@ -850,6 +1039,8 @@ def main(argv=None):
         else:
             metric, unit, value = "scenes/sec end-to-end reconstruction (ScanNet, %d^3 %s)" % (
                 cfgd["res"], "MISE" if args.upsampling_steps else "dense grid"), "scenes/s", value_all
+            if args.config == "demo":
+                metric = "scenes/sec, the reference's demo workload (objectness + NMS selection, dense 32^3 grids)"
         per = max(scenes_total, 1.0)
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
@@ -882,13 +1073,44 @@ def main(argv=None):
                          "note": "algorithmic FLOPs (1 312 768 per query point) over HIP-event time of the decoder "
                                  "launches inside the timed region; f16x3 issues 3x that on the MFMA pipe"},
         }
+        busy, busy_src = mfma_busy(args.mode)
+        out["roofline"]["mfma_busy"] = busy
+        out["roofline"]["mfma_busy_source"] = busy_src
+        if args.scenes:
+            out["config"]["sweep_scenes"] = args.scenes
+        modes = getattr(be, "modes", None)
+        if modes:
+            # configs[2]'s named quantities side by side: the parity mode (the headline of this line), the single-pass
+            # 16-bit mode, and the matrix-pipe-busy counter of each
+            for m in ("f16x3", "f16x1"):
+                modes[m]["mfma_busy"], _ = mfma_busy(m)
+            out["roofline"]["f16x3_back_to_back"] = modes["f16x3"]
+            out["roofline"]["f16x1"] = modes["f16x1"]
+        if args.config == "demo" and be.name == "hip":
+            shift, k0 = be.demo_calibration or (None, None)
+            out["config"].update({
+                "selection": "objectness > dump_threshold + class-aware 3-D NMS + empty-box removal (demo.py:223-234, "
+                             "ap_helper.py:131-264) on the device",
+                "objectness_bias_shift": shift, "proposals_kept_scene0": k0,
+                "placeholder_mean_sizes": bool(getattr(be, "placeholder_sizes", False)),
+                "graph_detect": ({"requested": True,
+                                  "captured_workers": sum(1 for g in be.graphs if g and "graph" in g),
+                                  "errors": sorted({g["error"] for g in be.graphs if g and "error" in g})}
+                                 if args.graph_detect else {"requested": False})})
+            recs = [r for r in (getattr(be, "last_scene_stats", None) or []) if not r.get("failed") and "ms" in r]
+            if recs:
+                keys = sorted(recs[0]["ms"])
+                out["stage_ms_per_scene"] = {k: sum(r["ms"][k] for r in recs) / len(recs) for k in keys}
+                out["stage_ms_per_scene"]["note"] = ("HIP-event times on each scene's own stream, %d scenes in flight: "
+                                                     "stages of different scenes overlap" % (be.S * be.NB))
         if be.name in ("hip", "stress") and not args.no_extras:
             out["roofline_grouping"] = grouping_roofline(be.device)
         if be.name == "hip" and not args.no_extras:
             out["roofline_fps"], out["roofline_ball_query"] = pointop_rooflines(be.device, be.scenes[min(be.scenes)])
         if single is not None:
             out["single_scene"] = {"scenes_in_flight": 1, "ms_per_scene": 1e3 * single,
-                                   "scenes_per_s": 1.0 / single}
+                                   "scenes_per_s": 1.0 / single,
+                                   "stage_ms": getattr(be, "single_stage_ms", None)}
         if world == 1 and not args.no_cpu_baseline and be.name != "stub":
             if all_cpus:
                 # the CPU legs (parity checker, CPU baseline) get EVERY host core back: the NUMA pinning above is for the

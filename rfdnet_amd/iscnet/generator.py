@@ -172,8 +172,11 @@ class Generator3D(object):
         bit-identical to what they would produce for every proposal) plus tile maps that make
         all K proposals read it.  Returns (pts, lin, tile_prop, tile_src, K * points)."""
         key = (res0, depth, float(box_size), K, str(dev))
-        c = self.__dict__.get('_round0_cache')
-        if c is None or c[0] != key:
+        cache = self.__dict__.setdefault('_round0_cache', {})      # per K: a selection (NMS) changes K from scene to scene
+        c = cache.get(key)
+        if c is None:
+            if len(cache) >= 64:
+                cache.clear()
             R1 = (res0 << depth) + 1
             ps = torch.empty(1, R1 ** 3, dtype=torch.uint8, device=dev)
             vs = torch.empty(1, _lib.lib().rfd_mise_vstate_elems(res0, depth), dtype=torch.uint8, device=dev)
@@ -191,8 +194,7 @@ class Generator3D(object):
             torch.cuda.current_stream(dev).synchronize()       # the scratch tensors die with this frame
             tile_prop = torch.arange(K, dtype=torch.int32, device=dev).repeat_interleave(tiles_per)
             tile_src = torch.arange(tiles_per, dtype=torch.int32, device=dev).repeat(K)
-            c = (key, (pts, lin, tile_prop, tile_src, K * n))
-            self.__dict__['_round0_cache'] = c
+            c = cache[key] = (key, (pts, lin, tile_prop, tile_src, K * n))
         return c[1]
 
     # ---- mesh extraction ------------------------------------------------------------

@@ -77,6 +77,30 @@ def numa_cpus_for_gpu(index, sys_root="/sys"):
         return None
 
 
+def numa_cpus_for_bdf(bdf, sys_root="/sys"):
+    """Host CPUs of the NUMA node of the PCI device `bdf` ("0000:f1:00.0"), None when unknown.  The answer HIP itself
+    gives for a device (torch.cuda.get_device_properties(i).pci_*) -- it does not depend on how KFD nodes, readable or
+    not, line up with HIP's device numbering, so a rank checks its pre-initialisation pinning
+    against it once the runtime is up (bench.py)."""
+    try:
+        with open(os.path.join(sys_root, "bus", "pci", "devices", bdf, "numa_node")) as fh:
+            node = int(fh.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sys_root, "devices", "system", "node", "node%d" % node, "cpulist")) as fh:
+            return _cpulist(fh.read()) or None
+    except (OSError, ValueError):
+        return None
+
+
+def device_bdf(props):
+    """PCI address of a torch device-properties object, None when this torch build does not expose it"""
+    try:
+        return "%04x:%02x:%02x.0" % (int(props.pci_domain_id), int(props.pci_bus_id), int(props.pci_device_id))
+    except (AttributeError, TypeError, ValueError):
+        return None
+
+
 def visible_device_index(local_rank, env=None):
     """Physical (KFD order) index of the GPU that HIP calls device `local_rank`, honouring HIP_VISIBLE_DEVICES /
     ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES remapping; None when a list is set that cannot be translated (UUIDs,
@@ -177,6 +201,104 @@ def launch_local_ranks(script, argv, nproc, env=None, timeout=None):
             return rc or 124
         time.sleep(0.05)
     return rc
+
+
+PREFLIGHT_FIELDS = ("rank", "device_index", "visible_devices", "pinned_cpus", "allowed_cpus", "numa_node_matches",
+                    "hw_queues", "free_gib", "library_ok")
+
+
+def preflight(rank, local_rank, world, stub=False, one_device=False, deadline_s=55.0, env=None):
+    """`bench.py --preflight`: can this job start?  Run by EVERY rank (the driver's first `--gpus 8` run is unattended):
+      1. local checks any rank can evaluate by itself, BEFORE the rendezvous, so that a mis-sized job fails on every rank
+         at once instead of hanging in it: ranks per node vs visible devices, the HIP library loads and is a gfx950 build,
+         the device is a gfx950 part;
+      2. the rendezvous + ONE all-gather of a small per-rank vector over the job's backend (RCCL over xGMI on GPUs, gloo
+         in the CPU tests) -- the collective the benchmark itself ends with -- with the process group's own time-out
+         inside the deadline;
+      3. a per-rank report: device index, CPUs pinned / allowed, whether the NUMA node of the pinning is the one HIP's
+         PCI address says, GPU_MAX_HW_QUEUES, free HBM.
+    Any failure prints ONE line `preflight FAILED [rank r]: <what> -- <what to do>` to stderr and exits non-zero; a
+    watchdog ends the process with the same kind of line if anything blocks past `deadline_s`.
+    Returns the gathered (world, len(PREFLIGHT_FIELDS)) array (rank 0 prints it as JSON)."""
+    import datetime
+    import threading
+    env = os.environ if env is None else env
+
+    def fail(what, fix, code=2):
+        sys.stderr.write("preflight FAILED [rank %d]: %s -- %s\n" % (rank, what, fix))
+        sys.stderr.flush()
+        os._exit(code)
+
+    dog = threading.Timer(deadline_s, lambda: fail(
+        "no answer within %.0f s (rendezvous or collective blocked)" % deadline_s,
+        "check that all %d ranks started, MASTER_ADDR=127.0.0.1 / MASTER_PORT agree, and HSA_ENABLE_IPC_MODE_LEGACY=0 "
+        "is exported" % world, 3))
+    dog.daemon = True
+    dog.start()
+    local_world = int(env.get("LOCAL_WORLD_SIZE", world))
+    fake = env.get("RFD_PREFLIGHT_FAKE_DEVICES")
+    if stub:
+        n_dev = int(fake) if fake else local_world
+    else:
+        n_dev = torch.cuda.device_count()
+    need = 1 if one_device else local_world
+    if n_dev < need:
+        fail("%d ranks on this node but %d visible GPU(s)" % (local_world, n_dev),
+             "launch with --nproc-per-node %d / --gpus %d, or widen HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES"
+             % (max(n_dev, 1), max(n_dev, 1)))
+    dev_index = 0 if one_device else local_rank
+    lib_ok, free_gib, numa_ok = 1.0, -1.0, -1.0
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else -1
+    pinned = allowed
+    device = torch.device("cpu")
+    if not stub:
+        try:
+            from . import _lib
+            arch = _lib.lib().rfd_build_arch().decode()
+        except Exception as e:
+            fail("librfd_hip.so does not load (%s)" % e, "run `python -c 'import __graft_entry__ as g; g.build()'`")
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+        props = torch.cuda.get_device_properties(dev_index)
+        gcn = getattr(props, "gcnArchName", "")
+        if arch not in gcn:
+            fail("device %d is %s (%s), the library is built for %s" % (dev_index, props.name, gcn, arch),
+                 "run on MI355X (gfx950) -- the kernels are written for that part only")
+        free, _ = torch.cuda.mem_get_info(dev_index)
+        free_gib = free / 2.0 ** 30
+        if free_gib < 24.0:
+            fail("only %.1f GiB of HBM free on device %d" % (free_gib, dev_index),
+                 "another process holds the GPU (rocm-smi --showpids); the 128^3 sweep keeps ~20 GiB resident")
+        want = numa_cpus_for_bdf(device_bdf(props) or "")
+        if want and hasattr(os, "sched_getaffinity"):
+            mine = os.sched_getaffinity(0)
+            numa_ok = 1.0 if set(mine) <= set(want) else 0.0
+    vec = [float(rank), float(dev_index), float(n_dev), float(pinned), float(allowed), numa_ok,
+           float(env.get("GPU_MAX_HW_QUEUES", "-1") or -1), free_gib, lib_ok]
+    gathered = None
+    if world > 1 or env.get("RFD_BENCH_FORCE_DIST") == "1":
+        import torch.distributed as dist
+        backend = "gloo" if (stub or one_device) else "nccl"
+        kw = {"device_id": device} if backend == "nccl" else {}
+        try:
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=max(10.0, deadline_s - 10.0)), **kw)
+            t = torch.tensor(vec, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            out = torch.empty(world * t.numel(), dtype=torch.float64, device=t.device)
+            dist.all_gather_into_tensor(out, t)
+            gathered = out.view(world, -1).cpu().numpy()
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:
+            fail("the %s rendezvous / all-gather failed (%s: %s)" % (backend, type(e).__name__, str(e)[:160]),
+                 "check MASTER_ADDR=127.0.0.1, a free MASTER_PORT, HSA_ENABLE_IPC_MODE_LEGACY=0, and that no rank died above")
+        ranks = sorted(int(r) for r in gathered[:, 0])
+        if ranks != list(range(world)):
+            fail("the all-gather returned ranks %s" % ranks, "every rank must run the same command line (RANK 0..%d)" % (world - 1))
+    else:
+        import numpy as np
+        gathered = np.asarray([vec])
+    dog.cancel()
+    return gathered
 
 
 def scene_ids_for_rank(n_scenes, rank, world_size):

@@ -225,3 +225,66 @@ def test_numa_lookup_skips_kfd_nodes_it_may_not_read(tmp_path):
     (n1 / "cpulist").write_text("64-127,192-255\n")
     cpus = sharding.numa_cpus_for_gpu(0, str(root))
     assert cpus is not None and cpus[0] == 64 and cpus[-1] == 255 and len(cpus) == 128
+
+
+def test_preflight_over_eight_gloo_ranks(tmp_path):
+    """`bench.py --preflight --gpus 8` -- every rank checks its devices, joins ONE all-gather over
+    the job's backend and reports its affinity / hardware-queue settings; rank 0 prints one JSON line, exit code 0."""
+    import time
+    t0 = time.time()
+    p = run_bench(["--preflight", "--gpus", "8"], GPU_MAX_HW_QUEUES="16")
+    assert p.returncode == 0, p.stderr
+    assert time.time() - t0 < 60
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["preflight"] == "ok" and out["n_gpus"] == 8
+    assert [int(r["rank"]) for r in out["ranks"]] == list(range(8))
+    assert all(int(r["hw_queues"]) == 16 and int(r["visible_devices"]) == 8 for r in out["ranks"])
+
+
+def test_preflight_fails_on_every_rank_with_one_actionable_line_when_there_are_fewer_devices_than_ranks():
+    """8 ranks, 4 visible devices: no rank may sit in the rendezvous -- each one sees the mismatch by itself, prints the
+    line that says what to do and exits non-zero, well inside 60 s."""
+    import time
+    t0 = time.time()
+    p = run_bench(["--preflight", "--gpus", "8"], RFD_PREFLIGHT_FAKE_DEVICES="4")
+    assert p.returncode != 0
+    assert time.time() - t0 < 60
+    lines = [l for l in p.stderr.splitlines() if l.startswith("preflight FAILED")]
+    assert lines and all("8 ranks on this node but 4 visible GPU(s)" in l and "--nproc-per-node 4" in l for l in lines)
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_preflight_watchdog_ends_a_rank_whose_peers_never_arrive():
+    """a rank alone in a world of 2 (its peer was never started): the rendezvous cannot complete; the rank must not
+    hang -- one actionable line, non-zero exit, inside the deadline"""
+    import time
+    from rfdnet_amd import sharding
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from rfdnet_amd import sharding\n"
+            "sharding.preflight(0, 0, 2, stub=True, deadline_s=6.0)\n" % ROOT)
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(sharding.free_port()))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and time.time() - t0 < 40
+    assert "preflight FAILED [rank 0]" in p.stderr
+
+
+def test_scenes_flag_sweeps_the_311_scan_split_over_eight_ranks(tmp_path):
+    """`bench.py --config mise128 --scenes 311 --gpus 8` = BASELINE configs[4] in one command: scene j of the sweep ->
+    rank j mod 8 (39 x 7 + 38), every scene exactly once, steps derived from the scene count."""
+    stats = str(tmp_path / "sweep.json")
+    p = run_bench(["--config", "mise128", "--scenes", "311", "--gpus", "8", "--warmup", "1", "--in-flight", "4",
+                   "--stats-out", stats])
+    assert p.returncode == 0, p.stderr
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["config"]["scenes_done"] == 311 and out["config"]["sweep_scenes"] == 311
+    assert out["steps"] == 10                               # ceil(311 / (8 ranks x 4 in flight))
+    first = 1 * 8 * 4                                       # the warm-up step's scenes come first
+    seen = []
+    for r in range(8):
+        d = json.load(open(stats if r == 0 else "%s.rank%d" % (stats, r)))
+        ids = sorted(i for s in d["scenes"] for i in s["scenes"])
+        assert ids == [first + j for j in range(r, 311, 8)], r
+        seen += ids
+    assert sorted(seen) == list(range(first, first + 311))
