@@ -112,9 +112,6 @@ def parse(argv=None):
     ap.add_argument("--demo-keep", type=int, default=16,
                     help="--config demo: the objectness bias of the seeded head is shifted so that this many of scene "
                          "0's 256 proposals pass the 0.5 threshold (NMS and empty-box removal then thin them out)")
-    ap.add_argument("--graph-detect", action="store_true",
-                    help="--config demo: replay the detection stage (backbone, voting, proposals) from a captured HIP "
-                         "graph per worker instead of ~150 launches per scene")
     args = ap.parse_args(argv)
     c = CONFIGS[args.config]
     for k in ("points", "resolution0", "upsampling_steps"):
@@ -262,7 +259,6 @@ class HipBackend(object):
         # generator state (round 3 built a full replica per worker)
         self.net = self._build_net()
         self.nets = [self.net] + [self.net.worker_view() for _ in range(self.S - 1)]
-        self.graphs = [None] * self.S           # --graph-detect: (graph, static input, static outputs) per worker
         self.timers = [DecodeTimer(self.net.completion.decoder)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.S)]
         self.sinks = [MeshSink(self.device) for _ in range(self.S)]
@@ -348,7 +344,7 @@ class HipBackend(object):
         if ev:
             ev[0].record()
         with torch.no_grad():
-            end_points, proposal_features = self.detect(w, net, pc)
+            end_points, proposal_features = net.detect(pc)
             if ev:
                 ev[4].record()
             sel = net.select_proposals(end_points, self.args.selection, pc)
@@ -392,37 +388,6 @@ class HipBackend(object):
                                        "meshes": len(meshes), "vertices": int(v.shape[0]), "triangles": int(f.shape[0]),
                                        "failed": False})
         return len(meshes), int(v.shape[0]), int(f.shape[0]), gen.stats.get('n_queries', 0)
-
-    def detect(self, w, net, pc):
-        """net.detect(pc); with --graph-detect the stage is captured ONCE per worker (on its own stream, after the
-        warm-up pass has built every lazily packed weight) and replayed from a HIP graph: one launch instead of the
-        ~150 of backbone + voting + proposal head (4 x [FPS, ball query, fused SA], 2 x [three_nn, interpolate, MLP],
-        the vote and proposal heads)."""
-        if not self.args.graph_detect or pc.shape[0] != 1:
-            return net.detect(pc)
-        torch = self.torch
-        g = self.graphs[w]
-        if g is None:
-            self.graphs[w] = g = {"calls": 0}
-        g["calls"] += 1
-        if "graph" not in g:
-            if g["calls"] < 2 or "error" in g:        # first pass of this worker: eager (builds the caches)
-                return net.detect(pc)
-            try:
-                static_in = pc.clone()
-                graph = torch.cuda.CUDAGraph()
-                torch.cuda.current_stream().synchronize()
-                with torch.cuda.graph(graph, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                    out = net.detect(static_in)
-                g.update(graph=graph, static_in=static_in, out=out)
-            except Exception as e:                    # not capturable on this stack: say so, stay eager
-                g["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
-                sys.stderr.write("[graph-detect] capture failed, staying eager: %s\n" % g["error"])
-                return net.detect(pc)
-        g["static_in"].copy_(pc)
-        g["graph"].replay()
-        end_points, feats = g["out"]
-        return dict(end_points), feats
 
     def scene_stats(self):
         """per-scene records of the timed region with the event times resolved (call after the final sync)"""
@@ -1093,10 +1058,9 @@ def main(argv=None):
                              "ap_helper.py:131-264) on the device",
                 "objectness_bias_shift": shift, "proposals_kept_scene0": k0,
                 "placeholder_mean_sizes": bool(getattr(be, "placeholder_sizes", False)),
-                "graph_detect": ({"requested": True,
-                                  "captured_workers": sum(1 for g in be.graphs if g and "graph" in g),
-                                  "errors": sorted({g["error"] for g in be.graphs if g and "error" in g})}
-                                 if args.graph_detect else {"requested": False})})
+                "launch_overhead_note": "a HIP graph of the detection stage was tried (round 5, GPU call 1): capture fails on "
+                                        "this stack (hipErrorStreamCaptureUnsupported inside the stage's library calls), and "
+                                        "the stage is 6.6 ms of FPS kernels out of 7.8 ms, so at most ~1 ms was at stake"})
             recs = [r for r in (getattr(be, "last_scene_stats", None) or []) if not r.get("failed") and "ms" in r]
             if recs:
                 keys = sorted(recs[0]["ms"])

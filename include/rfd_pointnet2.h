@@ -142,7 +142,7 @@ int rfd_stream_status_snapshot(void *stream, unsigned *host_word);
 int rfd_release_stream(void *stream);
 /* Multi-workgroup furthest point sampling (n > 4096 points per scene: the scene is spread over G <= 64 workgroups
  * that exchange their candidates every round) needs its G workgroups resident together.  Where they cannot be -- a
- * CU-masked stream, a partitioned GPU, another process's persistent kernel holding the CUs -- the launch does NOT
+ * partitioned GPU, a CU-masked queue, another stream's or process's persistent kernel holding the CUs -- the launch does NOT
  * hang: a workgroup that has polled `ms` milliseconds (wall clock; default 500, or RFD_FPS_TIMEOUT_MS at load) for
  * one round's candidates raises the launch's sticky abort word, every workgroup of the launch -- running, or
  * dispatched only later -- leaves at once, status bit 0 is raised on the stream and idxs keeps the caller's
@@ -154,11 +154,12 @@ int rfd_fps_set_timeout_ms(int ms);
  * 10 at 80 000 points = 32 workgroups).  Geometry sweeps (tools/fps_sweep.py) and tests; results never depend on
  * it.  Returns the previous value, -2 for a value that is not instantiated. */
 int rfd_fps_set_geometry(int points_per_thread);
-/* A HIP stream confined to compute units [first_cu, first_cu + n_cus) of the current device
- * (hipExtStreamCreateWithCUMask); the caller destroys it with rfd_stream_destroy.  Not used by the product path:
- * it is how tests/test_gpu_fps_abort.py makes a launch that cannot be co-resident. */
-int rfd_stream_create_cu_mask(int first_cu, int n_cus, void **stream);
-int rfd_stream_destroy(void *stream);
+/* TEST HOOK, not part of the product path: occupy all but `leave_free_cus` compute units of the current device with
+ * workgroups that each hold a CU's whole LDS, until *release_flag (device memory) becomes non-zero or max_ms (<= 10000)
+ * have passed -- a multi-workgroup FPS launched beside it cannot have all its workgroups resident, which is the
+ * situation the time-out above exists for (tests/test_gpu_fps_abort.py).  Returns the number of holding workgroups
+ * or a negative hipError. */
+int rfd_test_hold_cus(int leave_free_cus, const unsigned *release_flag, int max_ms, void *stream);
 /* "gfx950" etc. of the code object actually loaded. */
 const char *rfd_build_arch(void);
 

@@ -41,8 +41,7 @@ SIGNATURES = {
     "rfd_occ_set_launch_shape": [_i, _i, _i],
     "rfd_fps_set_timeout_ms": [_i],
     "rfd_fps_set_geometry": [_i],
-    "rfd_stream_create_cu_mask": [_i, _i, C.POINTER(C.c_void_p)],
-    "rfd_stream_destroy": [_f],
+    "rfd_test_hold_cus": [_i, _f, _i, _f],
     "rfd_make_grid_points": [_i, _fl, _fl, _fl, _f, _i, _f],
     "rfd_mise_init": [_i, _i, _i, _f, _f, _f],
     "rfd_mise_count": [_i, _i, _i, _f, _f, _f],
@@ -151,7 +150,7 @@ def _raise_status(st):
     msgs = []
     if st & 1:
         msgs.append("furthest point sampling aborted: its workgroups were not resident together within the "
-                    "exchange time-out (CU-masked stream / partitioned or oversubscribed GPU?)")
+                    "exchange time-out (partitioned / CU-masked / oversubscribed GPU?)")
     if st & 2:
         msgs.append("occupancy decoder: activation exceeded the f16 range")
     if st & 4:
@@ -209,15 +208,6 @@ class StatusSnapshot(object):
                     _snap_pool.append(self.buf)
             self.buf = None
         return self.value
-
-
-def cu_masked_stream(first_cu, n_cus):
-    """torch stream over a HIP stream confined to CUs [first_cu, first_cu + n_cus) (tests; see rfd_pointnet2.h).
-    Destroy with lib().rfd_stream_destroy(stream.cuda_stream)."""
-    import torch
-    h = C.c_void_p()
-    check(lib().rfd_stream_create_cu_mask(first_cu, n_cus, C.byref(h)), "rfd_stream_create_cu_mask")
-    return torch.cuda.ExternalStream(h.value)
 
 
 def release_stream(stream=None):

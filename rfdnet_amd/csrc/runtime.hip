@@ -165,33 +165,4 @@ RFD_API int rfd_fps_set_geometry(int points_per_thread) {
   return ws->fps_force_ppt.exchange(points_per_thread);
 }
 
-// A HIP stream confined to compute units [first_cu, first_cu + n_cus) of the current device
-// (hipExtStreamCreateWithCUMask).  Not used by the product path (partitioning the chip between the detection stage
-// and the decoder was measured and dropped: profiles/r04_cu_mask.txt); it is how the tests make a multi-workgroup
-// FPS launch that cannot be co-resident.  The caller destroys it with rfd_stream_destroy.
-RFD_API int rfd_stream_create_cu_mask(int first_cu, int n_cus, void **stream) {
-  RfdWorkspace *ws;
-  int rc = rfd_get_workspace(&ws);
-  if (rc) return rc;
-  const int ncu = ws->num_cu > 0 ? ws->num_cu : 256;
-  if (!stream || first_cu < 0 || n_cus <= 0 || first_cu + n_cus > ncu || ncu > 1024) {
-    rfd_set_error("rfd_stream_create_cu_mask: range", hipErrorInvalidValue);
-    return (int)hipErrorInvalidValue;
-  }
-  const int words = (ncu + 31) / 32;
-  uint32_t mask[32] = {0};
-  for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
-  hipStream_t s;
-  RFD_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
-  *stream = (void *)s;
-  return 0;
-}
-
-RFD_API int rfd_stream_destroy(void *stream) {
-  if (!stream) return 0;
-  (void)rfd_release_stream(stream);
-  RFD_CHECK(hipStreamDestroy((hipStream_t)stream));
-  return 0;
-}
-
 RFD_API const char *rfd_build_arch(void) { return "gfx950"; }

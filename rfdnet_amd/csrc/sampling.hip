@@ -310,6 +310,19 @@ __global__ void gather_points_grad_kernel(int c, int n, int m,
             grad_out[((size_t)bi * c + l) * m + j]);
 }
 
+// Test hook (rfd_test_hold_cus): one 64-thread workgroup per CU, each holding the CU's whole LDS, until *release != 0
+// or max_ticks of wall clock have passed -- so that nothing that needs LDS can be placed beside it.
+__global__ void hold_cus_kernel(const unsigned *release, u64 max_ticks) {
+  extern __shared__ unsigned char held[];
+  if (threadIdx.x == 0) {
+    held[0] = 1;
+    const u64 t0 = (u64)wall_clock64();
+    while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
+           (u64)wall_clock64() - t0 < max_ticks)
+      __builtin_amdgcn_s_sleep(32);
+  }
+}
+
 template <int PPT>
 int launch_fps(int nb, int n, int m, int G, int bs_log2, int cpb,
                const float *dataset, float *temp, int *idxs, float *new_xyz,
@@ -395,6 +408,34 @@ RFD_API int rfd_furthest_point_sampling_gather(int b, int n, int m,
                                                float *temp, int *idxs,
                                                float *new_xyz, void *stream) {
   return fps_impl(b, n, m, dataset, temp, idxs, new_xyz, stream);
+}
+
+// Test hook: occupy all but `leave_free_cus` compute units of the current device with workgroups that hold a CU's
+// whole LDS each, until *release_flag (device memory) becomes non-zero or max_ms have passed (hard upper bound: the
+// hook can never hang a device).  A multi-workgroup FPS launched beside it then CANNOT have all its workgroups
+// resident -- the situation rfd_fps_set_timeout_ms exists for (tests/test_gpu_fps_abort.py).  Returns the number of
+// holding workgroups (> 0) or a negative hipError.
+RFD_API int rfd_test_hold_cus(int leave_free_cus, const unsigned *release_flag, int max_ms, void *stream) {
+  RfdWorkspace *ws;
+  int rc = rfd_get_workspace(&ws);
+  if (rc) return -rc;
+  int dev = 0, lds_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -(int)hipErrorInvalidDevice;
+  (void)hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev);
+  if (lds_cu <= 0) lds_cu = 160 * 1024;
+  const int n = ws->num_cu - leave_free_cus;
+  if (!release_flag || leave_free_cus < 0 || n <= 0 || max_ms <= 0 || max_ms > 10000) {
+    rfd_set_error("rfd_test_hold_cus: arguments", hipErrorInvalidValue);
+    return -(int)hipErrorInvalidValue;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hold_cus_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_cu);
+  if (e != hipSuccess) { rfd_set_error("rfd_test_hold_cus: hipFuncSetAttribute", e); return -(int)e; }
+  hipLaunchKernelGGL(hold_cus_kernel, dim3(n), dim3(64), (size_t)lds_cu, (hipStream_t)stream, release_flag,
+                     (u64)max_ms * (u64)ws->wall_clock_khz);
+  e = hipGetLastError();
+  if (e != hipSuccess) { rfd_set_error("rfd_test_hold_cus", e); return -(int)e; }
+  return n;
 }
 
 RFD_API int gather_points_kernel_wrapper(int b, int c, int n, int npoints,
