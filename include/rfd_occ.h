@@ -129,6 +129,14 @@ int rfd_mise_scatter(int n_tiles, int res0, int depth, const int *tile_prop,
 int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
                        const float *values, unsigned char *pstate,
                        unsigned char *vstate, void *stream);
+/* The same pass, told how many points of each proposal the round just decoded has evaluated (`evaluated` [K], device:
+ * the counts rfd_mise_count produced for that round; NULL = every proposal, as above).  A proposal with none is left
+ * alone -- the reference stops calling update() / subdivide_voxels() for an object as soon as its query() is empty
+ * (generator.py:104-117), so its octree never changes again.  Same results, and the tail rounds of a deep octree touch
+ * a handful of proposals instead of all K lattices. */
+int rfd_mise_subdivide_active(int K, int res0, int depth, double threshold, const float *values,
+                              unsigned char *pstate, unsigned char *vstate, const int *evaluated,
+                              void *stream);
 /* to_dense (mise.pyx:133-163): forward-fill along x, then y, then z.  pstate is working
  * storage here: its content after the call is unspecified (only `values` is the result). */
 int rfd_mise_to_dense(int K, int res0, int depth, float *values,

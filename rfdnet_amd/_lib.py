@@ -48,6 +48,7 @@ SIGNATURES = {
     "rfd_mise_collect": [_i, _i, _i, _f, _f, _f, _fl, _f, _f, _f],
     "rfd_mise_scatter": [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f],
     "rfd_mise_subdivide": [_i, _i, _i, C.c_double, _f, _f, _f, _f],
+    "rfd_mise_subdivide_active": [_i, _i, _i, C.c_double, _f, _f, _f, _f, _f],
     "rfd_mise_to_dense": [_i, _i, _i, _f, _f, _f],
     "rfd_points_in_boxes": [_i, _i, _i, _i, _f, _f, _f, _f],
     "rfd_nms3d": [_i, _i, C.c_double, _i, _i, _f, _f, _f, _f, _f, _f],

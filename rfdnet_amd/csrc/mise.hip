@@ -250,12 +250,14 @@ __global__ void mise_subdivide_kernel(int R1, int res0, int depth, int l, double
                                       size_t n_per, size_t v_per,
                                       const float *__restrict__ values,
                                       unsigned char *__restrict__ pstate,
-                                      unsigned char *__restrict__ vstate) {
+                                      unsigned char *__restrict__ vstate,
+                                      const int *__restrict__ evaluated) {
   const int nl = res0 << l;
   const size_t nvox = cube((size_t)nl);
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nvox) return;
   const int kp = blockIdx.y;
+  if (evaluated && evaluated[kp] == 0) return;      // see mise_subdivide_lds_kernel
   unsigned char *vs = vstate + (size_t)kp * v_per + vstate_offset(res0, l);
   if (vs[e] != 1) return;  // not a leaf (mise.pyx:236,245)
   const int s = 1 << (depth - l);
@@ -303,7 +305,7 @@ constexpr int SUB_TJ = 8, SUB_TK = 32;
 __global__ __launch_bounds__(SUB_TJ * SUB_TK) void mise_subdivide_lds_kernel(
     int R1, int res0, int depth, int l, double thr, size_t n_per, size_t v_per, size_t total_bytes,
     const float *__restrict__ values, unsigned char *__restrict__ pstate,
-    unsigned char *__restrict__ vstate) {
+    unsigned char *__restrict__ vstate, const int *__restrict__ evaluated) {
   extern __shared__ unsigned char flags[];
   const int nl = res0 << l;
   const int s = 1 << (depth - l);
@@ -312,6 +314,19 @@ __global__ __launch_bounds__(SUB_TJ * SUB_TK) void mise_subdivide_lds_kernel(
   const int vk0 = (tile % tiles_k) * SUB_TK, vj0 = ((tile / tiles_k) % tiles_j) * SUB_TJ;
   const int vi = tile / (tiles_k * tiles_j);
   const int kp = blockIdx.y;
+  // Nothing was evaluated for this proposal in the round that has just been decoded: its points and voxels are exactly
+  // as the previous subdivision pass left them, and that pass found nothing more to split (it would have queued
+  // points) -- the whole proposal is a no-op.  (The tail rounds of a deep octree touch a handful of proposals.)
+  if (evaluated && evaluated[kp] == 0) return;
+  // A slab without a single leaf voxel of this level has nothing to decide either: skip it BEFORE its grid points are
+  // staged.  At 128^3 the level-1 voxels exist only around the surface (~3 % of the 64^3 lattice), yet every round
+  // staged all 869 M points of the level through the byte-granular path below: 27 ms per scene.
+  unsigned char *vs = vstate + (size_t)kp * v_per + vstate_offset(res0, l);
+  const int tk = threadIdx.x % SUB_TK, tj = threadIdx.x / SUB_TK;
+  const int vk = vk0 + tk, vj = vj0 + tj;
+  const size_t e = ((size_t)vi * nl + vj) * nl + vk;
+  const bool leaf = vk < nl && vj < nl && vs[e] == 1;       // mise.pyx:236,245
+  if (!__syncthreads_or(leaf)) return;
   unsigned char *ps = pstate + (size_t)kp * n_per;
   const float *vals = values + (size_t)kp * n_per;
   const int PK = SUB_TK * s + 1, PJ = SUB_TJ * s + 1;
@@ -371,12 +386,7 @@ __global__ __launch_bounds__(SUB_TJ * SUB_TK) void mise_subdivide_lds_kernel(
     }
   }
   __syncthreads();
-  const int tk = threadIdx.x % SUB_TK, tj = threadIdx.x / SUB_TK;
-  const int vk = vk0 + tk, vj = vj0 + tj;
-  if (vk >= nl || vj >= nl) return;
-  unsigned char *vs = vstate + (size_t)kp * v_per + vstate_offset(res0, l);
-  const size_t e = ((size_t)vi * nl + vj) * nl + vk;
-  if (vs[e] != 1) return;  // not a leaf (mise.pyx:236,245)
+  if (!leaf) return;
   unsigned any = 0;
   for (int a = 0; a <= s; ++a)
     for (int b = 0; b <= s; ++b)
@@ -589,9 +599,8 @@ RFD_API int rfd_mise_scatter(int n_tiles, int res0, int depth, const int *tile_p
   return 0;
 }
 
-RFD_API int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
-                               const float *values, unsigned char *pstate,
-                               unsigned char *vstate, void *stream) {
+static int mise_subdivide(int K, int res0, int depth, double threshold, const float *values,
+                          unsigned char *pstate, unsigned char *vstate, const int *evaluated, void *stream) {
   if (K <= 0 || depth <= 0) return 0;
   const int R1 = (res0 << depth) + 1;
   const size_t n_per = cube((size_t)R1);
@@ -606,16 +615,31 @@ RFD_API int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
       const size_t lds = (size_t)(sl + 1) * (SUB_TJ * sl + 1) * (SUB_TK * sl + 1);
       hipLaunchKernelGGL(mise_subdivide_lds_kernel, dim3(tiles, K), dim3(SUB_TJ * SUB_TK), lds,
                          (hipStream_t)stream, R1, res0, depth, l, threshold, n_per, v_per,
-                         n_per * (size_t)K, values, pstate, vstate);
+                         n_per * (size_t)K, values, pstate, vstate, evaluated);
       RFD_CHECK_LAUNCH();
       continue;
     }
     hipLaunchKernelGGL(mise_subdivide_kernel, dim3((unsigned)((nvox + 255) / 256), K), dim3(256), 0,
                        (hipStream_t)stream, R1, res0, depth, l, threshold, n_per, v_per, values,
-                       pstate, vstate);
+                       pstate, vstate, evaluated);
     RFD_CHECK_LAUNCH();
   }
   return 0;
+}
+
+RFD_API int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
+                               const float *values, unsigned char *pstate,
+                               unsigned char *vstate, void *stream) {
+  return mise_subdivide(K, res0, depth, threshold, values, pstate, vstate, nullptr, stream);
+}
+
+// The same pass told how many points of each proposal the round just decoded has evaluated (`evaluated` [K] on the
+// device: the counts rfd_mise_count produced for that round): a proposal with none is skipped -- nothing about it
+// has changed since the previous pass.  Identical results; the caller passes NULL for round 0.
+RFD_API int rfd_mise_subdivide_active(int K, int res0, int depth, double threshold,
+                                      const float *values, unsigned char *pstate,
+                                      unsigned char *vstate, const int *evaluated, void *stream) {
+  return mise_subdivide(K, res0, depth, threshold, values, pstate, vstate, evaluated, stream);
 }
 
 RFD_API int rfd_mise_to_dense(int K, int res0, int depth, float *values,

@@ -312,10 +312,11 @@ __global__ void gather_points_grad_kernel(int c, int n, int m,
 
 // Test hook (rfd_test_hold_cus): one 64-thread workgroup per CU, each holding the CU's whole LDS, until *release != 0
 // or max_ticks of wall clock have passed -- so that nothing that needs LDS can be placed beside it.
+constexpr int CU_LDS_BYTES = 160 * 1024;      // gfx950: the whole LDS of a compute unit
 __global__ void hold_cus_kernel(const unsigned *release, u64 max_ticks) {
-  extern __shared__ unsigned char held[];
+  __shared__ unsigned char held[CU_LDS_BYTES];
   if (threadIdx.x == 0) {
-    held[0] = 1;
+    reinterpret_cast<volatile unsigned char *>(held)[CU_LDS_BYTES - 1] = 1;      // keep the allocation
     const u64 t0 = (u64)wall_clock64();
     while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
            (u64)wall_clock64() - t0 < max_ticks)
@@ -419,21 +420,16 @@ RFD_API int rfd_test_hold_cus(int leave_free_cus, const unsigned *release_flag, 
   RfdWorkspace *ws;
   int rc = rfd_get_workspace(&ws);
   if (rc) return -rc;
-  int dev = 0, lds_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return -(int)hipErrorInvalidDevice;
-  (void)hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev);
-  if (lds_cu <= 0) lds_cu = 160 * 1024;
   const int n = ws->num_cu - leave_free_cus;
   if (!release_flag || leave_free_cus < 0 || n <= 0 || max_ms <= 0 || max_ms > 10000) {
     rfd_set_error("rfd_test_hold_cus: arguments", hipErrorInvalidValue);
     return -(int)hipErrorInvalidValue;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hold_cus_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_cu);
-  if (e != hipSuccess) { rfd_set_error("rfd_test_hold_cus: hipFuncSetAttribute", e); return -(int)e; }
-  hipLaunchKernelGGL(hold_cus_kernel, dim3(n), dim3(64), (size_t)lds_cu, (hipStream_t)stream, release_flag,
+  // (static LDS of exactly one CU's worth: the device attribute MaxSharedMemoryPerMultiprocessor reports 64 KiB on this
+  // stack, and two holders then shared a CU and left half the chip free)
+  hipLaunchKernelGGL(hold_cus_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, release_flag,
                      (u64)max_ms * (u64)ws->wall_clock_khz);
-  e = hipGetLastError();
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) { rfd_set_error("rfd_test_hold_cus", e); return -(int)e; }
   return n;
 }

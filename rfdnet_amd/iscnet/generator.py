@@ -157,8 +157,10 @@ class Generator3D(object):
                 _call("rfd_mise_scatter", dev, n_tiles, res0, depth, tile_prop.data_ptr(),
                       tile_src.data_ptr() if tile_src is not None else None, lin.data_ptr(),
                       logits.data_ptr(), values.data_ptr(), pstate.data_ptr())
-            _call("rfd_mise_subdivide", dev, K, res0, depth, float(thr), values.data_ptr(),
-                  pstate.data_ptr(), vstate.data_ptr())
+            # proposals whose query was empty this round are finished (the reference's per-object loop has ended for
+            # them, generator.py:104): the pass skips them; round 0 evaluates every proposal's lattice
+            _call("rfd_mise_subdivide_active", dev, K, res0, depth, float(thr), values.data_ptr(),
+                  pstate.data_ptr(), vstate.data_ptr(), None if shared else counts.data_ptr())
             n_queries += total
             per_round.append(total)
             rounds += 1
