@@ -42,6 +42,7 @@ SIGNATURES = {
     "rfd_fps_set_timeout_ms": [_i],
     "rfd_fps_set_geometry": [_i],
     "rfd_test_hold_cus": [_i, _f, _i, _f],
+    "rfd_fps_test_phantom_units": [_i],
     "rfd_make_grid_points": [_i, _fl, _fl, _fl, _f, _i, _f],
     "rfd_mise_init": [_i, _i, _i, _f, _f, _f],
     "rfd_mise_count": [_i, _i, _i, _f, _f, _f],

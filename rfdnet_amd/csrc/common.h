@@ -61,6 +61,7 @@ struct RfdWorkspace {
   std::atomic<int> fps_timeout_ms;  // multi-workgroup FPS: a workgroup that has polled this long for a round's
                                     // candidates aborts the launch (status bit 0); rfd_fps_set_timeout_ms
   std::atomic<int> fps_force_ppt;   // 0 = the launcher's own geometry; else points per thread (rfd_fps_set_geometry)
+  std::atomic<int> fps_test_phantom;  // exchange units that never publish (rfd_fps_test_phantom_units; tests only)
 };
 int rfd_get_workspace(RfdWorkspace **ws);
 // The status slot (0..RFD_STATUS_SLOTS-1) of `stream`: the slot it already owns, else a free one it claims now,

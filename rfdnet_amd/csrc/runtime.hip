@@ -48,6 +48,7 @@ int rfd_get_workspace(RfdWorkspace **out) {
     const int to_ms = to ? atoi(to) : 0;
     w->fps_timeout_ms.store(to_ms > 0 ? to_ms : RFD_FPS_TIMEOUT_MS_DEFAULT);
     w->fps_force_ppt.store(0);
+    w->fps_test_phantom.store(0);
     g_ws[dev] = w;
   }
   *out = g_ws[dev];
@@ -163,6 +164,15 @@ RFD_API int rfd_fps_set_geometry(int points_per_thread) {
     default: return -2;
   }
   return ws->fps_force_ppt.exchange(points_per_thread);
+}
+
+// TEST HOOK: every round of a multi-workgroup FPS launch also waits for `n` exchange units that nobody publishes -- the
+// deterministic way to drive a launch into its exchange time-out (what a workgroup that is never dispatched looks like
+// to the resident ones).  0 = off.  Returns the previous value.
+RFD_API int rfd_fps_test_phantom_units(int n) {
+  RfdWorkspace *ws;
+  if (rfd_get_workspace(&ws)) return -1;
+  return ws->fps_test_phantom.exchange(n < 0 ? 0 : n > 8 ? 8 : n);
 }
 
 RFD_API const char *rfd_build_arch(void) { return "gfx950"; }

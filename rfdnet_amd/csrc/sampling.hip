@@ -102,7 +102,7 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_log2, int cpb) {
 
 template <int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
-    int n, int m, int G, int bs_log2, int cpb, const float *__restrict__ dataset,
+    int n, int m, int G, int Gw, int bs_log2, int cpb, const float *__restrict__ dataset,
     float *__restrict__ temp, int *__restrict__ idxs,
     float *__restrict__ new_xyz, u64 *region, unsigned *status, u64 timeout_ticks) {
   const int batch = blockIdx.x / G;
@@ -114,7 +114,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
   idxs += (size_t)batch * m;
   if (new_xyz) new_xyz += (size_t)batch * m * 3;
   u64 *abort_word = region;  // one per launch: any scene's time-out ends them all
-  u64 *slots = region + FPS_REGION_HEAD + (size_t)batch * G * 10;  // [g][parity][5]
+  // Gw = exchange units a round waits for: G, or more when a test asks for units that never publish
+  // (rfd_fps_test_phantom_units: the deterministic way into the time-out path)
+  u64 *slots = region + FPS_REGION_HEAD + (size_t)batch * Gw * 10;  // [g][parity][5]
 
   __shared__ int s_abort;
   // a wave's candidate: {key lo, key hi, k, x} and {y, z}; [parity][wave]
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
       u64 t_first = 0;
       for (;;) {
         bool ok = true;
-        if (lane < G) {
+        if (lane < Gw) {
           const u64 g0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const u64 g1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const u64 g2 = __hip_atomic_load(theirs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -325,13 +327,13 @@ __global__ void hold_cus_kernel(const unsigned *release, u64 max_ticks) {
 }
 
 template <int PPT>
-int launch_fps(int nb, int n, int m, int G, int bs_log2, int cpb,
+int launch_fps(int nb, int n, int m, int G, int Gw, int bs_log2, int cpb,
                const float *dataset, float *temp, int *idxs, float *new_xyz,
                u64 *region, unsigned *status, u64 timeout_ticks, hipStream_t s) {
   // (packing the G exchanging workgroups onto one XCD -- launching 8x the blocks
   // and using every 8th -- was measured 15 % SLOWER than letting them spread)
   hipLaunchKernelGGL(fps_kernel<PPT>, dim3(nb * G), dim3(FPS_THREADS), 0, s, n,
-                     m, G, bs_log2, cpb, dataset, temp, idxs, new_xyz, region,
+                     m, G, Gw, bs_log2, cpb, dataset, temp, idxs, new_xyz, region,
                      status, timeout_ticks);
   RFD_CHECK_LAUNCH();
   return 0;
@@ -369,7 +371,12 @@ int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
   int bs_log2 = 0;
   while ((1 << bs_log2) < bs) ++bs_log2;
   const int cpb = ceil_div(n, bs);
-  const int batches_per_launch = G > 1 ? (FPS_MAX_WG / G) : b;
+  int Gw = G;
+  if (G > 1) {
+    const int phantom = ws->fps_test_phantom.load(std::memory_order_relaxed);
+    Gw = G + phantom > 64 ? 64 : G + phantom;
+  }
+  const int batches_per_launch = G > 1 ? (FPS_MAX_WG / Gw) : b;
   const u64 timeout_ticks = (u64)ws->fps_timeout_ms.load(std::memory_order_relaxed) * (u64)ws->wall_clock_khz;
   unsigned *status = rfd_status_word(ws, s);
   for (int b0 = 0; b0 < b; b0 += batches_per_launch) {
@@ -378,14 +385,14 @@ int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
     if (G > 1) {
       // this stream's own region (launches on a stream are serial); abort word + exchange granules zeroed per launch
       region = rfd_fps_region(ws, s);
-      RFD_CHECK(hipMemsetAsync(region, 0, sizeof(u64) * (FPS_REGION_HEAD + (size_t)nb * G * 10), s));
+      RFD_CHECK(hipMemsetAsync(region, 0, sizeof(u64) * (FPS_REGION_HEAD + (size_t)nb * Gw * 10), s));
     }
     const float *ds = dataset + (size_t)b0 * n * 3;
     float *tp = temp + (size_t)b0 * n;
     int *ix = idxs + (size_t)b0 * m;
     float *nx = new_xyz ? new_xyz + (size_t)b0 * m * 3 : nullptr;
     switch (ppt) {
-#define FPS_CASE(P) case P: rc = launch_fps<P>(nb, n, m, G, bs_log2, cpb, ds, tp, ix, nx, region, status, timeout_ticks, s); break;
+#define FPS_CASE(P) case P: rc = launch_fps<P>(nb, n, m, G, Gw, bs_log2, cpb, ds, tp, ix, nx, region, status, timeout_ticks, s); break;
       FPS_CASE(1) FPS_CASE(2) FPS_CASE(4) FPS_CASE(5) FPS_CASE(8) FPS_CASE(10) FPS_CASE(16) FPS_CASE(20) FPS_CASE(32) FPS_CASE(40) FPS_CASE(64)
 #undef FPS_CASE
       default: rc = (int)hipErrorInvalidValue;

@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# HIP streams share GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one queue serialise: tests that need two
+# streams to run side by side (tests/test_gpu_fps_abort.py: a kernel holding the CUs beside the launch under test) would
+# measure the queue, not the kernels.  Read by the runtime when it initialises, so set before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
