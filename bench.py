@@ -265,6 +265,10 @@ class HipBackend(object):
         # scene pool: global scene id i -> seed 10 + (i mod pool), pool a multiple of the world size so
         # that a rank always meets the same resident scenes (its residue class)
         self.pool = world * 2 * self.S * self.NB
+        if getattr(args, "scenes", None):
+            # a sweep meets (up to 320) DISTINCT scenes, like the split it stands in for, not eight of them over and over
+            total = args.warmup * self.S * self.NB * world + args.scenes
+            self.pool = world * (-(-min(total, 320) // world))
         self.world = world
         self.scenes = {}
         for i in sharding.scene_ids_for_rank(self.pool, rank, world):
