@@ -40,23 +40,28 @@ typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Wave-wide unsigned max with DPP (no LDS crossbar traffic): prefix max inside
-// each 16-lane row (row_shr 1,2,4,8), row 0->1 / 2->3 (row_bcast:15), then
-// 1->2,3 (row_bcast:31); lane 63 holds the result, read back through an SGPR.
-// Lanes a control does not reach keep `old` = their own value (max identity).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_max(unsigned v) {
-  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
-  return o > v ? o : v;
-}
-
+// Wave-wide unsigned max with DPP (no LDS crossbar traffic): prefix max inside each 16-lane row (row_shr 1,2,4,8),
+// row 0->1 / 2->3 (row_bcast:15), then 1->2,3 (row_bcast:31); lane 63 holds the result, read back through an SGPR.
+// The DPP control sits ON the v_max_u32 (a lane whose source lane does not exist, or that the row mask excludes, keeps
+// its value: bound_ctrl off), one instruction per step behind the two wait states a DPP read of a fresh VALU result
+// needs.  Written out by hand: from `update_dpp` + max hipcc makes v_mov, s_nop, v_mov_dpp, v_max per step, and this
+// chain runs two to four times in every one of the m serial rounds (round 5: see profiles/r05_fps_sweep.txt).
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  v = dpp_max<0x111, 0xf>(v);  // row_shr:1
-  v = dpp_max<0x112, 0xf>(v);  // row_shr:2
-  v = dpp_max<0x114, 0xf>(v);  // row_shr:4
-  v = dpp_max<0x118, 0xf>(v);  // row_shr:8
-  v = dpp_max<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-  v = dpp_max<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
@@ -100,7 +105,8 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_log2, int cpb) {
 #define FPS_STAMP(i) do { } while (0)
 #endif
 
-template <int PPT>
+// MULTI = false: one workgroup holds the scene (no exchange code at all in the instantiation).
+template <int PPT, bool MULTI>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
     int n, int m, int G, int Gw, int bs_log2, int cpb, const float *__restrict__ dataset,
     float *__restrict__ temp, int *__restrict__ idxs,
@@ -122,6 +128,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
   // a wave's candidate: {key lo, key hi, k, x} and {y, z}; [parity][wave]
   __shared__ __attribute__((aligned(16))) u32x4 s_a[2][FPS_WAVES];
   __shared__ __attribute__((aligned(8))) f32x2 s_yz[2][FPS_WAVES];
+  // the round's global winner, written by the polling wave: same layout; [parity]
+  __shared__ __attribute__((aligned(16))) u32x4 s_win[2];
+  __shared__ __attribute__((aligned(8))) f32x2 s_winyz[2];
 
   // ---- load this thread's points once; they stay in registers ----
   float px[PPT], py[PPT], pz[PPT], td[PPT];
@@ -180,96 +189,113 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
       s_yz[par][wave] = f32x2{w.y, w.z};
     }
     __syncthreads();
-    // all four candidates in ONE round of broadcast reads (left to itself hipcc makes every payload read conditional
-    // on the key comparison before it: four dependent LDS round trips per round), then register selects
-    u32x4 ca[FPS_WAVES];
-    f32x2 cyz[FPS_WAVES];
-#pragma unroll
-    for (int q = 0; q < FPS_WAVES; ++q) { ca[q] = s_a[par][q]; cyz[q] = s_yz[par][q]; }
-    int gave_up = s_abort;
-#pragma unroll
-    for (int q = 0; q < FPS_WAVES; ++q) asm volatile("" : "+v"(ca[q]), "+v"(cyz[q]));
-    asm volatile("" : "+v"(gave_up));
-    // a wave of this workgroup gave up in the previous round's exchange (below): everybody leaves here, together
-    if (G > 1 && gave_up) break;
     Cand b;
-    b.key = ((u64)ca[0].y << 32) | ca[0].x; b.k = (int)ca[0].z;
-    b.x = __uint_as_float(ca[0].w); b.y = cyz[0].x; b.z = cyz[0].y;
+    b.key = 0; b.k = 0; b.x = p0x; b.y = p0y; b.z = p0z;
+    if (!MULTI || wave == 0) {
+      // all four candidates in ONE round of broadcast reads (left to itself hipcc makes every payload read
+      // conditional on the key comparison before it: four dependent LDS round trips per round), then register selects
+      u32x4 ca[FPS_WAVES];
+      f32x2 cyz[FPS_WAVES];
 #pragma unroll
-    for (int q = 1; q < FPS_WAVES; ++q) {
-      const u64 kq = ((u64)ca[q].y << 32) | ca[q].x;
-      const bool better = kq > b.key;
-      b.key = better ? kq : b.key;
-      b.k = better ? (int)ca[q].z : b.k;
-      b.x = better ? __uint_as_float(ca[q].w) : b.x;
-      b.y = better ? cyz[q].x : b.y;
-      b.z = better ? cyz[q].y : b.z;
+      for (int q = 0; q < FPS_WAVES; ++q) { ca[q] = s_a[par][q]; cyz[q] = s_yz[par][q]; }
+#pragma unroll
+      for (int q = 0; q < FPS_WAVES; ++q) asm volatile("" : "+v"(ca[q]), "+v"(cyz[q]));
+      b.key = ((u64)ca[0].y << 32) | ca[0].x; b.k = (int)ca[0].z;
+      b.x = __uint_as_float(ca[0].w); b.y = cyz[0].x; b.z = cyz[0].y;
+#pragma unroll
+      for (int q = 1; q < FPS_WAVES; ++q) {
+        const u64 kq = ((u64)ca[q].y << 32) | ca[q].x;
+        const bool better = kq > b.key;
+        b.key = better ? kq : b.key;
+        b.k = better ? (int)ca[q].z : b.k;
+        b.x = better ? __uint_as_float(ca[q].w) : b.x;
+        b.y = better ? cyz[q].x : b.y;
+        b.z = better ? cyz[q].y : b.z;
+      }
     }
     FPS_STAMP(3);
-    if (G > 1) {
-      // ---- publish this workgroup's candidate: 5 tagged granules ----
-      u64 *mine = slots + ((size_t)g * 2 + par) * 5;
-      if (t < 5) {
-        unsigned payload = (unsigned)(b.key >> 32);
-        payload = t == 1 ? (b.key ? (unsigned)b.k : 0xffffffffu) : payload;
-        payload = t == 2 ? __float_as_uint(b.x) : payload;
-        payload = t == 3 ? __float_as_uint(b.y) : payload;
-        payload = t == 4 ? __float_as_uint(b.z) : payload;
-        __hip_atomic_store(mine + t, ((u64)(unsigned)j << 32) | payload,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      FPS_STAMP(4);
-      // ---- every wave gathers all G candidates (lane = workgroup) ----
-      const u64 *theirs = slots + ((size_t)lane * 2 + par) * 5;
-      unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
-      unsigned spins = 0;
-      u64 t_first = 0;
-      for (;;) {
-        bool ok = true;
-        if (lane < Gw) {
-          const u64 g0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const u64 g1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const u64 g2 = __hip_atomic_load(theirs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const u64 g3 = __hip_atomic_load(theirs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const u64 g4 = __hip_atomic_load(theirs + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned tag = (unsigned)j;
-          ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag &&
-               (unsigned)(g2 >> 32) == tag && (unsigned)(g3 >> 32) == tag &&
-               (unsigned)(g4 >> 32) == tag;
-          f0 = (unsigned)g0; f1 = (unsigned)g1; f2 = (unsigned)g2;
-          f3 = (unsigned)g3; f4 = (unsigned)g4;
+    if constexpr (MULTI) {
+      // ONE wave of the workgroup runs the exchange; the other three sleep at the barrier below.  (Round 5, GPU call
+      // 11: four pollers per CU queue behind each other in the CU's memory path -- the guide's hand-off table: 0.8 us
+      // idle, 1.2-1.5 us with 2-5 waves streaming on the endpoint CU -- 5.19 -> 4.95 ms at SA1 for one poller + a second
+      // barrier.)
+      if (wave == 0) {
+        // ---- publish this workgroup's candidate: 5 tagged granules ----
+        u64 *mine = slots + ((size_t)g * 2 + par) * 5;
+        if (t < 5) {
+          unsigned payload = (unsigned)(b.key >> 32);
+          payload = t == 1 ? (b.key ? (unsigned)b.k : 0xffffffffu) : payload;
+          payload = t == 2 ? __float_as_uint(b.x) : payload;
+          payload = t == 3 ? __float_as_uint(b.y) : payload;
+          payload = t == 4 ? __float_as_uint(b.z) : payload;
+          __hip_atomic_store(mine + t, ((u64)(unsigned)j << 32) | payload,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (__all(ok)) break;
-        if ((++spins % FPS_SLOW_POLLS) == 0) {
-          // slow path: somebody is late.  Leave -- for good, the whole launch -- when another workgroup has
-          // already given up or this wave has waited out the time-out itself (wall clock, not a poll count: a poll
-          // takes anything from 0.3 to several us depending on what else uses the memory system).
-          const u64 now = (u64)wall_clock64();
-          if (t_first == 0) t_first = now;
-          const bool dead = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-          if (dead || now - t_first > timeout_ticks) {
-            if (lane == 0) {
-              __hip_atomic_store(abort_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              atomicOr(status, 1u);
-              s_abort = 1;
-            }
-            break;  // this round's "winner" is garbage; the flag is read behind the next round's barrier
+        FPS_STAMP(4);
+        // ---- gather all G candidates (lane = workgroup) ----
+        const u64 *theirs = slots + ((size_t)lane * 2 + par) * 5;
+        unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
+        unsigned spins = 0;
+        u64 t_first = 0;
+        for (;;) {
+          bool ok = true;
+          if (lane < Gw) {
+            const u64 g0 = __hip_atomic_load(theirs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 g1 = __hip_atomic_load(theirs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 g2 = __hip_atomic_load(theirs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 g3 = __hip_atomic_load(theirs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 g4 = __hip_atomic_load(theirs + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned tag = (unsigned)j;
+            ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag &&
+                 (unsigned)(g2 >> 32) == tag && (unsigned)(g3 >> 32) == tag &&
+                 (unsigned)(g4 >> 32) == tag;
+            f0 = (unsigned)g0; f1 = (unsigned)g1; f2 = (unsigned)g2;
+            f3 = (unsigned)g3; f4 = (unsigned)g4;
           }
+          if (__all(ok)) break;
+          if ((++spins % FPS_SLOW_POLLS) == 0) {
+            // slow path: somebody is late.  Leave -- for good, the whole launch -- when another workgroup has
+            // already given up or this wave has waited out the time-out itself (wall clock, not a poll count: a poll
+            // takes anything from 0.3 to several us depending on what else uses the memory system).
+            const u64 now = (u64)wall_clock64();
+            if (t_first == 0) t_first = now;
+            const bool dead = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (dead || now - t_first > timeout_ticks) {
+              if (lane == 0) {
+                __hip_atomic_store(abort_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(status, 1u);
+                s_abort = 1;
+              }
+              break;  // this round's "winner" is garbage; everybody reads the flag behind the barrier below
+            }
+          }
+          __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_s_sleep(1);
+        FPS_STAMP(5);
+        // a workgroup without a valid point publishes k = -1; rank is recomputed
+        // from k so ties between workgroups order exactly as in the CUDA tree
+        Cand o;
+        const bool valid = lane < G && (int)f1 >= 0;
+        o.key = valid ? (((u64)f0 << 32) | (u64)(~fps_rank((int)f1, bs_log2, cpb))) : 0ull;
+        o.k = (int)f1;
+        o.x = __uint_as_float(f2);
+        o.y = __uint_as_float(f3);
+        o.z = __uint_as_float(f4);
+        b = wave_select(o);
+        FPS_STAMP(6);
+        if (lane == 0) {
+          s_win[par] = u32x4{(unsigned)b.key, (unsigned)(b.key >> 32), (unsigned)b.k, __float_as_uint(b.x)};
+          s_winyz[par] = f32x2{b.y, b.z};
+        }
       }
-      FPS_STAMP(5);
-      // a workgroup without a valid point publishes k = -1; rank is recomputed
-      // from k so ties between workgroups order exactly as in the CUDA tree
-      Cand o;
-      const bool valid = lane < G && (int)f1 >= 0;
-      o.key = valid ? (((u64)f0 << 32) | (u64)(~fps_rank((int)f1, bs_log2, cpb))) : 0ull;
-      o.k = (int)f1;
-      o.x = __uint_as_float(f2);
-      o.y = __uint_as_float(f3);
-      o.z = __uint_as_float(f4);
-      b = wave_select(o);
-      FPS_STAMP(6);
+      __syncthreads();
+      u32x4 wa = s_win[par];
+      f32x2 wyz = s_winyz[par];
+      int gave_up = s_abort;
+      asm volatile("" : "+v"(wa), "+v"(wyz), "+v"(gave_up));
+      if (gave_up) break;      // the polling wave gave up (time-out / the launch's abort word): everybody leaves, together
+      b.key = ((u64)wa.y << 32) | wa.x; b.k = (int)wa.z;
+      b.x = __uint_as_float(wa.w); b.y = wyz.x; b.z = wyz.y;
     }
     if (b.key == 0ull) { b.k = 0; b.x = p0x; b.y = p0y; b.z = p0z; }  // all skipped
     cx = b.x; cy = b.y; cz = b.z;  // old = dists_i[0] (:170)
@@ -326,13 +352,13 @@ __global__ void hold_cus_kernel(const unsigned *release, u64 max_ticks) {
   }
 }
 
-template <int PPT>
+template <int PPT, bool MULTI>
 int launch_fps(int nb, int n, int m, int G, int Gw, int bs_log2, int cpb,
                const float *dataset, float *temp, int *idxs, float *new_xyz,
                u64 *region, unsigned *status, u64 timeout_ticks, hipStream_t s) {
   // (packing the G exchanging workgroups onto one XCD -- launching 8x the blocks
   // and using every 8th -- was measured 15 % SLOWER than letting them spread)
-  hipLaunchKernelGGL(fps_kernel<PPT>, dim3(nb * G), dim3(FPS_THREADS), 0, s, n,
+  hipLaunchKernelGGL((fps_kernel<PPT, MULTI>), dim3(nb * G), dim3(FPS_THREADS), 0, s, n,
                      m, G, Gw, bs_log2, cpb, dataset, temp, idxs, new_xyz, region,
                      status, timeout_ticks);
   RFD_CHECK_LAUNCH();
@@ -391,12 +417,20 @@ int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
     float *tp = temp + (size_t)b0 * n;
     int *ix = idxs + (size_t)b0 * m;
     float *nx = new_xyz ? new_xyz + (size_t)b0 * m * 3 : nullptr;
-    switch (ppt) {
-#define FPS_CASE(P) case P: rc = launch_fps<P>(nb, n, m, G, Gw, bs_log2, cpb, ds, tp, ix, nx, region, status, timeout_ticks, s); break;
-      FPS_CASE(1) FPS_CASE(2) FPS_CASE(4) FPS_CASE(5) FPS_CASE(8) FPS_CASE(10) FPS_CASE(16) FPS_CASE(20) FPS_CASE(32) FPS_CASE(40) FPS_CASE(64)
-#undef FPS_CASE
-      default: rc = (int)hipErrorInvalidValue;
+#define FPS_CASE(P, M) case P: rc = launch_fps<P, M>(nb, n, m, G, Gw, bs_log2, cpb, ds, tp, ix, nx, region, status, timeout_ticks, s); break;
+    if (G > 1) {
+      switch (ppt) {
+        FPS_CASE(5, true) FPS_CASE(8, true) FPS_CASE(10, true) FPS_CASE(16, true) FPS_CASE(20, true) FPS_CASE(32, true)
+        FPS_CASE(40, true) FPS_CASE(64, true)
+        default: rc = (int)hipErrorInvalidValue;
+      }
+    } else {
+      switch (ppt) {
+        FPS_CASE(1, false) FPS_CASE(2, false) FPS_CASE(4, false) FPS_CASE(8, false) FPS_CASE(16, false)
+        default: rc = (int)hipErrorInvalidValue;
+      }
     }
+#undef FPS_CASE
     if (rc) return rc;
   }
   return 0;
