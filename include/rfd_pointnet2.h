@@ -143,10 +143,12 @@ int rfd_release_stream(void *stream);
 /* Multi-workgroup furthest point sampling (n > 4096 points per scene: the scene is spread over G <= 64 workgroups
  * that exchange their candidates every round) needs its G workgroups resident together.  Where they cannot be -- a
  * partitioned GPU, a CU-masked queue, another stream's or process's persistent kernel holding the CUs -- the launch does NOT
- * hang: a workgroup that has polled `ms` milliseconds (wall clock; default 500, or RFD_FPS_TIMEOUT_MS at load) for
- * one round's candidates raises the launch's sticky abort word, every workgroup of the launch -- running, or
+ * hang: a workgroup whose polling wave has waited `ms` milliseconds (wall clock; default 500, or RFD_FPS_TIMEOUT_MS at
+ * load) for one round's candidates raises the launch's sticky abort word, every workgroup of the launch -- running, or
  * dispatched only later -- leaves at once, status bit 0 is raised on the stream and idxs keeps the caller's
- * zero-fill beyond the round reached.  The reference's answer to a launch that cannot run is to fail fast as well
+ * zero-fill beyond the round reached.  (Measured on MI355X: beside a kernel that holds most CUs the hardware usually
+ * places NONE of the grid's workgroups and the launch just waits for the CUs, as any launch would; a partially placed
+ * grid -- seen with 8 free CUs on the null stream -- ends through the abort.)  The reference's answer to a launch that cannot run is to fail fast as well
  * (cuda_utils.h:30-39: message + exit); here the host raises and the device stays usable.  Returns the previous
  * value; ms <= 0 restores the default. */
 int rfd_fps_set_timeout_ms(int ms);
