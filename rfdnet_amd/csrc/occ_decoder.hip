@@ -177,19 +177,6 @@ __device__ __forceinline__ void dma_piece(const half8 *__restrict__ packed, unsi
       (lds_void *)(s_slots + (h & 3) * HALF_BYTES + frag * 1024), 16, 0, 0);
 }
 
-#ifdef RFD_DECODE_TRACE
-// debug build only (tools/dec_trace.py): wave 0 / lane 0 of the first tiles
-// overwrite their logits with s_memtime stamps of block 1's phases.
-#define TRACE_STAMP(slot)                                                              \
-  do {                                                                                 \
-    if (blk == 1 && wave == 0 && lane == 0 && tile < 64)                               \
-      reinterpret_cast<unsigned long long *>(logits)[(size_t)tile * 64 + (slot)] =     \
-          __builtin_amdgcn_s_memtime();                                                \
-  } while (0)
-#else
-#define TRACE_STAMP(slot) do { } while (0)
-#endif
-
 template <int TERMS>
 __global__ __launch_bounds__(256) void occ_decode_kernel(
     int n_tiles, const float *__restrict__ pts, const int *__restrict__ tile_prop,
@@ -261,7 +248,6 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
   half8 ahi[16], alo[16];  // B fragments of the block input, ks = 0..15
   for (int blk = 0; blk < NB; ++blk) {
     const float *S0 = s_tab + (1 + 4 * blk) * H, *T0 = S0 + H, *S1 = T0 + H, *T1 = S1 + H;
-    TRACE_STAMP(0);
     // ---- a' = relu(S0' H' + T0') for all 256 channels, fused with fc_0 of the
     // block's first 32 output channels: k-steps 2kb, 2kb+1 only need channel
     // block kb, so block kb+1 is converted in the shadow of their six MFMAs.
@@ -277,7 +263,6 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
         ahi[0] = words_to_frag(hw, 0); ahi[1] = words_to_frag(hw, 4);
         alo[0] = words_to_frag(lw, 0); alo[1] = words_to_frag(lw, 4);
       }
-      TRACE_STAMP(1);
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
         unsigned hw[8], lw[8];
@@ -319,13 +304,11 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
         }
       }
     }
-    TRACE_STAMP(2);
     // the slot just read is refilled by this iteration's LDS-DMA below
     __syncthreads();
 
     for (int mb = 0; mb < 8; ++mb) {
       const int c = blk * 8 + mb;  // global chunk
-      TRACE_STAMP(3 + 5 * mb);
       // ---- phase A: epilogue of fc_0 block mb, in the shadow of fc_0 block mb+1
       const EpiTab tb = load_epi_tab(S1, T1, 32 * mb + 4 * half);
       unsigned hw[8], lw[8];
@@ -392,7 +375,6 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
           if (h < N_HALVES || has_next) dma_piece(packed, s_slots, h, j & 7, wave, lane);
         }
       }
-      TRACE_STAMP(4 + 5 * mb);
       const half8 bhi0 = words_to_frag(hw, 0), bhi1 = words_to_frag(hw, 4);
       const half8 blo0 = words_to_frag(lw, 0), blo1 = words_to_frag(lw, 4);
       // ---- phase B: H'[ob] += fc_1[32ob.., 32mb..32mb+31] a2', two output blocks
@@ -433,12 +415,9 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      TRACE_STAMP(5 + 5 * mb);
       // prefetched halves landed + everyone done with the slots refilled next
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      TRACE_STAMP(6 + 5 * mb);
       __syncthreads();
-      TRACE_STAMP(7 + 5 * mb);
       acc_cur = acc_next;
     }
   }
@@ -463,9 +442,6 @@ __global__ __launch_bounds__(256) void occ_decode_kernel(
     }
   }
   part += __shfl_xor(part, 32);
-#ifdef RFD_DECODE_TRACE
-  if (tile >= 64)
-#endif
   if (half == 0) logits[pidx] = part + fc_out_b;
   }  // persistent tile loop
   // 0x7bff = 65504 = largest finite f16: the round-to-zero conversion saturates there

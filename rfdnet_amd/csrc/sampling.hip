@@ -95,16 +95,6 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_log2, int cpb) {
   return rev * (unsigned)cpb + ((unsigned)k >> bs_log2);
 }
 
-#ifdef RFD_FPS_TRACE
-#define FPS_STAMP(i)                                                                         \
-  do {                                                                                       \
-    if (j >= 100 && j < 104 && t == 0 && g == 0)                                             \
-      reinterpret_cast<unsigned long long *>(temp)[(j - 100) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define FPS_STAMP(i) do { } while (0)
-#endif
-
 // MULTI = false: one workgroup holds the scene (no exchange code at all in the instantiation).
 template <int PPT, bool MULTI>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
@@ -163,7 +153,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
 
   for (int j = 1; j < m; ++j) {
     const int par = j & 1;
-    FPS_STAMP(0);
     // ---- local update + argmax over this thread's points ----
     Cand c;
     c.key = 0; c.k = 0; c.x = p0x; c.y = p0y; c.z = p0z;
@@ -180,10 +169,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
       c.y = better ? py[i] : c.y;
       c.z = better ? pz[i] : c.z;
     }
-    FPS_STAMP(1);
     // ---- wave argmax, then workgroup argmax through LDS ----
     Cand w = wave_select(c);
-    FPS_STAMP(2);
     if (lane == 0) {
       s_a[par][wave] = u32x4{(unsigned)w.key, (unsigned)(w.key >> 32), (unsigned)w.k, __float_as_uint(w.x)};
       s_yz[par][wave] = f32x2{w.y, w.z};
@@ -213,7 +200,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
         b.z = better ? cyz[q].y : b.z;
       }
     }
-    FPS_STAMP(3);
     if constexpr (MULTI) {
       // ONE wave of the workgroup runs the exchange; the other three sleep at the barrier below.  (Round 5, GPU call
       // 11: four pollers per CU queue behind each other in the CU's memory path -- the guide's hand-off table: 0.8 us
@@ -231,7 +217,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
           __hip_atomic_store(mine + t, ((u64)(unsigned)j << 32) | payload,
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        FPS_STAMP(4);
         // ---- gather all G candidates (lane = workgroup) ----
         const u64 *theirs = slots + ((size_t)lane * 2 + par) * 5;
         unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;
@@ -271,7 +256,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
           }
           __builtin_amdgcn_s_sleep(1);
         }
-        FPS_STAMP(5);
         // a workgroup without a valid point publishes k = -1; rank is recomputed
         // from k so ties between workgroups order exactly as in the CUDA tree
         Cand o;
@@ -282,7 +266,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
         o.y = __uint_as_float(f3);
         o.z = __uint_as_float(f4);
         b = wave_select(o);
-        FPS_STAMP(6);
         if (lane == 0) {
           s_win[par] = u32x4{(unsigned)b.key, (unsigned)(b.key >> 32), (unsigned)b.k, __float_as_uint(b.x)};
           s_winyz[par] = f32x2{b.y, b.z};
@@ -305,13 +288,11 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
     }
   }
   // the CUDA kernel leaves the final min-distances in temp
-#ifndef RFD_FPS_TRACE
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = base + i * FPS_THREADS;
     if (k < n) temp[k] = nrank[i] ? td[i] : 1e10f;
   }
-#endif
 }
 
 __global__ void gather_points_kernel(int c, int n, int m,

@@ -70,6 +70,7 @@ def test_shipped_kernels_carry_no_wrong_result_switch_and_the_ablation_patch_reb
     for name in sorted(os.listdir(csrc)):
         text = open(os.path.join(csrc, name)).read()
         assert not re.search(r"\bDEC8_[A-Z]", text), name
+        assert not re.search(r"\bRFD_\w*TRACE\b", text), name          # the s_memtime stamp builds are patches too
         if name.endswith(".hip"):
             # getenv only in initialisers that run once per process (static locals / constructors)
             for m in re.finditer(r"getenv\(", text):
@@ -79,6 +80,14 @@ def test_shipped_kernels_carry_no_wrong_result_switch_and_the_ablation_patch_reb
     shipped = _asm(tmp_path, "occ_decoder8.hip", "dec8_shipped.s")
     patched = _asm(tmp_path, _ablation_source(tmp_path), "dec8_patched.s")
     assert _code_lines(shipped) == _code_lines(patched)
+    # the two phase-stamp patches (tools/fps_trace.py, tools/dec_trace.py) still apply and compile with their switch
+    import build_variants
+    for src, patch, flag in (("sampling.hip", "fps_trace.patch", "-DRFD_FPS_TRACE"),
+                             ("occ_decoder.hip", "dec4_trace.patch", "-DRFD_DECODE_TRACE")):
+        traced = build_variants.patched_source(src, patch, str(tmp_path / "trace_src"))
+        text = open(_asm(tmp_path, traced, src + ".trace.s", (flag,))).read()
+        assert "s_memtime" in text, src
+        assert "s_memtime" not in open(_asm(tmp_path, src, src + ".plain.s")).read(), src
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),

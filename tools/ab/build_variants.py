@@ -21,13 +21,31 @@ PATCH = os.path.join(ROOT, "tools", "ab", "dec8_ablation.patch")
 DEC8 = os.path.join(B.CSRC, "occ_decoder8.hip")
 
 
-def patched_decoder_source(out_dir):
-    """-> path of a copy of occ_decoder8.hip with the ablation switches patched back in (compile with -I csrc)"""
+def patched_source(src_name, patch_name, out_dir):
+    """-> path of a scratch copy of rfdnet_amd/csrc/<src_name> with tools/ab/<patch_name> applied (compile with -I csrc).
+    The patches hold every build switch that makes a kernel compute something else than the product does: the decoder's
+    ablation switches (dec8_ablation.patch) and the s_memtime phase stamps of tools/fps_trace.py / tools/dec_trace.py
+    (fps_trace.patch, dec4_trace.patch: RFD_FPS_TRACE / RFD_DECODE_TRACE overwrite an output buffer with time stamps)."""
     os.makedirs(out_dir, exist_ok=True)
-    dst = os.path.join(out_dir, "occ_decoder8.hip")
-    shutil.copyfile(DEC8, dst)
-    subprocess.check_call(["patch", "--quiet", "--no-backup-if-mismatch", "-p0", dst, PATCH])
+    dst = os.path.join(out_dir, src_name)
+    shutil.copyfile(os.path.join(B.CSRC, src_name), dst)
+    subprocess.check_call(["patch", "--quiet", "--no-backup-if-mismatch", "-p0", dst,
+                           os.path.join(ROOT, "tools", "ab", patch_name)])
     return dst
+
+
+def patched_decoder_source(out_dir):
+    """-> path of a copy of occ_decoder8.hip with the ablation switches patched back in"""
+    return patched_source("occ_decoder8.hip", "dec8_ablation.patch", out_dir)
+
+
+def build_patched(so_path, src_name, patch_name, flags):
+    """today's library with ONE source replaced by its patched copy, built with `flags` -> so_path"""
+    src = patched_source(src_name, patch_name, os.path.join(B.LIB_DIR, "variants", "src"))
+    srcs = [src if os.path.basename(s) == src_name else s for s in B.sources()]
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + B.HIPCC_FLAGS + ["-I" + B.CSRC] + list(flags) +
+                          ["-o", so_path] + srcs)
+    return so_path
 
 
 def variant_sources(out_dir):

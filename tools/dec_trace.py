@@ -12,9 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rfdnet_amd import _lib, build, synthetic  # noqa: E402
 
-so = os.path.join(ROOT, "rfdnet_amd", "lib", "librfd_hip_trace.so")
-if not os.path.exists(so) or "--rebuild" in sys.argv:
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DRFD_DECODE_TRACE", "-o", so] + build.sources())
+# the stamps are not in the product source: tools/ab/dec4_trace.patch puts them into a scratch copy of occ_decoder.hip
+sys.path.insert(0, os.path.join(ROOT, "tools", "ab"))
+import build_variants  # noqa: E402
+so = os.path.join(ROOT, "rfdnet_amd", "lib", "variants", "librfd_dec4_trace.so")
+if not os.path.exists(so) or "--rebuild" in sys.argv or "--build-only" in sys.argv:
+    build_variants.build_patched(so, "occ_decoder.hip", "dec4_trace.patch", ["-DRFD_DECODE_TRACE"])
 if "--build-only" in sys.argv:
     sys.exit(0)
 _lib.LIB_PATH = so

@@ -4,8 +4,12 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rfdnet_amd import _lib, build, synthetic
-so = os.path.join(ROOT, "rfdnet_amd", "lib", "librfd_hip_trace.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DRFD_FPS_TRACE", "-o", so] + build.sources())
+# the stamps are not in the product source: tools/ab/fps_trace.patch puts them into a scratch copy of sampling.hip
+sys.path.insert(0, os.path.join(ROOT, "tools", "ab"))
+import build_variants  # noqa: E402
+so = os.path.join(ROOT, "rfdnet_amd", "lib", "variants", "librfd_fps_trace.so")
+if not os.path.exists(so) or "--build-only" in sys.argv or "--rebuild" in sys.argv:
+    build_variants.build_patched(so, "sampling.hip", "fps_trace.patch", ["-DRFD_FPS_TRACE"])
 if "--build-only" in sys.argv:
     sys.exit(0)
 _lib.LIB_PATH = so
