@@ -6,7 +6,9 @@ failure mode (a register read before its hand-issued load has landed shows up on
 caches / first-touch page faults).
 
   kernels: gemm_rows8 (row-owner split-precision GEMM, with and without fused pooling),
-           the tile GEMM, occ_decode (4 waves), occ_decode8 (8 waves), sa_fused, the fused PointNet chains.
+           the tile GEMM, occ_decode (4 waves), occ_decode8 (8 waves), sa_fused, the fused PointNet chains,
+           and (round 5) furthest point sampling: the multi-workgroup exchange (one polling wave per workgroup,
+           tagged granules through memory, hand-written DPP reductions) and a single-workgroup level.
 """
 import os
 import sys
@@ -151,6 +153,29 @@ def check_chain(seed):
     return worst
 
 
+def check_fps(seed):
+    """SA1 of the headline scene (80 000 -> 2048, 32 workgroups exchanging candidates every round) from a cold context,
+    twice: bit-equal to the reference-run fixture F_NET80k (the reference's backbone on the oracle ops) and to itself;
+    a single-workgroup level (2048 -> 512) against the oracle."""
+    from oracle import oracle
+    from rfdnet_amd.pointnet2_ops import _ext
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "F_NET80k.npz"))
+    sc_seed, n_raw, n_pts = (int(v) for v in fx["pc_seed"])
+    pc = synthetic.synthetic_scene(seed=sc_seed, n_raw=n_raw, n_points=n_pts)
+    xyz = np.ascontiguousarray(pc[None, :, :3])
+    x = torch.from_numpy(xyz).cuda()
+    a = _ext.furthest_point_sampling(x, 2048)
+    b = _ext.furthest_point_sampling(x, 2048)
+    assert torch.equal(a, b), "FPS 80000 -> 2048: two runs differ in %d picks" % int((a != b).sum())
+    ref = fx["bb_sa1_inds"].reshape(1, -1).astype(np.int32)
+    got = a.cpu().numpy()
+    assert np.array_equal(got, ref), "FPS 80000 -> 2048: first wrong pick at round %d" % int(np.argmax(got[0] != ref[0]))
+    sub = np.ascontiguousarray(xyz[:, (seed * 997) % 70000:][:, :2048])
+    c = _ext.furthest_point_sampling(torch.from_numpy(sub).cuda(), 512).cpu().numpy()
+    assert np.array_equal(c, oracle.furthest_point_sampling(sub, 512)), "FPS 2048 -> 512 differs from the oracle"
+    return 0.0
+
+
 def check_sa_fused(seed):
     from rfdnet_amd import sa_fused
     from rfdnet_amd.pointnet2_ops.pointnet2_modules import PointnetSAModuleVotes
@@ -179,8 +204,9 @@ def main():
     assert torch.cuda.is_available()
     # cold start on purpose: the kernels under test are the FIRST launches of this context
     order = [lambda: ("gemm", check_gemm(seed)), lambda: ("decoders", check_decoders()),
-             lambda: ("sa_fused", check_sa_fused(seed)), lambda: ("chain", check_chain(seed))]
-    order = order[seed % 4:] + order[:seed % 4]           # rotate which kernel meets the coldest state
+             lambda: ("sa_fused", check_sa_fused(seed)), lambda: ("chain", check_chain(seed)),
+             lambda: ("fps", check_fps(seed))]
+    order = order[seed % 5:] + order[:seed % 5]           # rotate which kernel meets the coldest state
     if seed % 7 == 3:                                     # seeds 3, 10, 17 of the twenty
         order = [lambda: ("decoder_stress", check_decoder_stress())] + order
     res = [f() for f in order]

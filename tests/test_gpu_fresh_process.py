@@ -1,5 +1,5 @@
 """GPU (-m gpu): twenty fresh processes, each running gemm_rows8 / the tile GEMM / both decoders /
-the fused SA layer ONCE from a cold context against their references (tests/fresh_process_check.py).
+the fused SA layer / the fused chains / furthest point sampling ONCE from a cold context against their references (tests/fresh_process_check.py).
 Warm loops cannot catch a read of a register whose hand-issued load has not landed yet; the
 withdrawn fused ResnetBlockFC kernel of round 1 failed exactly this way in 1 of 14 cold runs."""
 import os
