@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 TILE = 128
 
 
-def gpu_mise(hip, fields, res0, depth, thr):
+def gpu_mise(hip, fields, res0, depth, thr, active=False):
     """Drive csrc/mise.hip exactly as the generator does, but with analytic
     fields evaluated on the host (so the oracle sees identical values)."""
     lib = hip.lib()
@@ -61,8 +61,14 @@ def gpu_mise(hip, fields, res0, depth, thr):
         hip.check(lib.rfd_mise_scatter(n_tiles, res0, depth, tile_prop.data_ptr(), None, lin.data_ptr(),
                                        torch.from_numpy(logits).cuda().data_ptr(), values.data_ptr(),
                                        pstate.data_ptr(), st), "scatter")
-        hip.check(lib.rfd_mise_subdivide(K, res0, depth, float(thr), values.data_ptr(), pstate.data_ptr(),
-                                         vstate.data_ptr(), st), "subdivide")
+        if active:
+            # the generator's entry point: a proposal whose query was empty this round is finished (the reference ends
+            # that object's loop, generator.py:104) and is skipped; `counts` = what this round evaluated
+            hip.check(lib.rfd_mise_subdivide_active(K, res0, depth, float(thr), values.data_ptr(), pstate.data_ptr(),
+                                                    vstate.data_ptr(), counts.data_ptr(), st), "subdivide_active")
+        else:
+            hip.check(lib.rfd_mise_subdivide(K, res0, depth, float(thr), values.data_ptr(), pstate.data_ptr(),
+                                             vstate.data_ptr(), st), "subdivide")
     hip.check(lib.rfd_mise_to_dense(K, res0, depth, values.data_ptr(), pstate.data_ptr(), st), "dense")
     return values.view(K, R1, R1, R1).cpu().numpy(), per_round
 
@@ -97,12 +103,17 @@ def plane_on_threshold(p, R):   # exact zeros: exercises the non-strict >= / <= 
     return (p[:, 0] - R // 2).astype(np.float64)
 
 
+@pytest.mark.parametrize("active", [False, True])
 @pytest.mark.parametrize("res0,depth", [(4, 1), (8, 2), (16, 1), (4, 3), (32, 1), (32, 2)])
-def test_batched_mise_equals_octree_oracle(hip, oracle, res0, depth):
-    """(32, 1) = the headline 64^3; (32, 2) = the 128^3 sweep configuration (configs[4])."""
+def test_batched_mise_equals_octree_oracle(hip, oracle, res0, depth, active):
+    """(32, 1) = the headline 64^3; (32, 2) = the 128^3 sweep configuration (configs[4]).  active: through
+    rfd_mise_subdivide_active, which skips the proposals that evaluated nothing this round (the six fields finish after
+    one to five rounds, so every round of the deeper cases has finished and unfinished proposals side by side)."""
     fields = [sphere(0.35), two_blobs, thin_slab, plane_on_threshold,
               lambda p, R: -np.ones(p.shape[0]), sphere(0.2, (0.4, 0.55, 0.6))]
-    dense, rounds = gpu_mise(hip, fields, res0, depth, 0.0)
+    dense, rounds = gpu_mise(hip, fields, res0, depth, 0.0, active=active)
+    if active:
+        assert len({sum(1 for r in rounds if r[k] > 0) for k in range(len(fields))}) > 1 or depth == 1
     for k, f in enumerate(fields):
         ref, counts = oracle_mise(oracle, f, res0, depth, 0.0)
         np.testing.assert_array_equal(dense[k].astype(np.float64), ref)
