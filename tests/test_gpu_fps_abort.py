@@ -177,3 +177,26 @@ def test_fps_geometries_are_bit_exact(hip, oracle, ppt):
         hip.lib().rfd_fps_set_geometry(0)
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
     np.testing.assert_array_equal(tmp.cpu().numpy(), rtemp)
+
+
+@pytest.mark.parametrize("b,n,m,ppt", [(3, 20000, 333, 5), (3, 20000, 333, 16), (2, 5001, 1, 8), (2, 9999, 2500, 10),
+                                       (4, 70001, 97, 20), (1, 300000, 64, 32)])
+def test_forced_geometries_on_odd_shapes_and_batches(hip, oracle, b, n, m, ppt):
+    """several scenes per launch (each with its own G exchange units in ONE region), sizes that are no multiple of
+    anything, m = 1, duplicates and near-origin points -- against the oracle, geometry forced"""
+    rng = np.random.default_rng(n + m + ppt)
+    p = rng.uniform(-2, 2, (b, n, 3)).astype(np.float32)
+    p[:, rng.integers(0, n, n // 50)] = p[:, rng.integers(0, n, n // 50)]                  # duplicates (exact ties)
+    p[:, rng.integers(0, n, 8)] = rng.uniform(-0.01, 0.01, (8, 3)).astype(np.float32)      # skipped points
+    ref = oracle.furthest_point_sampling(p, m)
+    x = torch.from_numpy(p).cuda()
+    out = torch.zeros(b, m, dtype=torch.int32, device="cuda")
+    tmp = torch.empty(b, n, device="cuda")
+    assert hip.lib().rfd_fps_set_geometry(ppt) >= 0
+    try:
+        hip.check(hip.lib().furthest_point_sampling_kernel_wrapper(b, n, m, x.data_ptr(), tmp.data_ptr(), out.data_ptr(),
+                                                                   hip.current_stream()), "fps")
+        hip.device_status()
+    finally:
+        hip.lib().rfd_fps_set_geometry(0)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
