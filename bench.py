@@ -1062,9 +1062,10 @@ def main(argv=None):
                              "ap_helper.py:131-264) on the device",
                 "objectness_bias_shift": shift, "proposals_kept_scene0": k0,
                 "placeholder_mean_sizes": bool(getattr(be, "placeholder_sizes", False)),
-                "launch_overhead_note": "a HIP graph of the detection stage was tried (round 5, GPU call 1): capture fails on "
-                                        "this stack (hipErrorStreamCaptureUnsupported inside the stage's library calls), and "
-                                        "the stage is 6.6 ms of FPS kernels out of 7.8 ms, so at most ~1 ms was at stake"})
+                "launch_overhead_note": "one scene = ~375 launches, yet the detection stage's 7.1 ms are 5.9 ms of FPS kernels "
+                                        "(latency-bound rounds) + 0.9 ms of other kernels: launch overhead is not what bounds "
+                                        "it; a HIP graph of the stage was tried (round 5, GPU call 1) and does not capture on "
+                                        "this stack (hipErrorStreamCaptureUnsupported inside the stage's library calls)"})
             recs = [r for r in (getattr(be, "last_scene_stats", None) or []) if not r.get("failed") and "ms" in r]
             if recs:
                 keys = sorted(recs[0]["ms"])
