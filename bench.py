@@ -1062,10 +1062,9 @@ def main(argv=None):
                              "ap_helper.py:131-264) on the device",
                 "objectness_bias_shift": shift, "proposals_kept_scene0": k0,
                 "placeholder_mean_sizes": bool(getattr(be, "placeholder_sizes", False)),
-                "launch_overhead_note": "one scene = ~375 launches, yet the detection stage's 7.1 ms are 5.9 ms of FPS kernels "
-                                        "(latency-bound rounds) + 0.9 ms of other kernels: launch overhead is not what bounds "
-                                        "it; a HIP graph of the stage was tried (round 5, GPU call 1) and does not capture on "
-                                        "this stack (hipErrorStreamCaptureUnsupported inside the stage's library calls)"})
+                "launch_overhead_note": "one scene = ~375 launches, yet the detection stage is kernel-bound: captured into a HIP "
+                                        "graph and replayed it takes 6.734 ms against 6.736 ms eager, bit-equal outputs "
+                                        "(profiles/r05_graph_probe.txt: FPS is 5.9 ms of it) -- a graph does not pay"})
             recs = [r for r in (getattr(be, "last_scene_stats", None) or []) if not r.get("failed") and "ms" in r]
             if recs:
                 keys = sorted(recs[0]["ms"])
