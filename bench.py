@@ -1087,18 +1087,22 @@ def main(argv=None):
                     os.sched_setaffinity(0, all_cpus)
                 except OSError:
                     pass
-            from oracle import cpu_baseline                       # the checker's CPU port, timed beside
+            # the checker's CPU port, timed beside -- in a FRESH interpreter with the full affinity mask and explicit
+            # OpenMP settings: workers created in THIS process under the NUMA pinning keep that mask (rounds 4-5: 128
+            # workers on one node's cores, MLP legs 10x slower)
+            from oracle import cpu_baseline
             if stress:
-                out["cpu_baseline"] = cpu_baseline.run_decoder_only()
+                out["cpu_baseline"] = cpu_baseline.run_isolated("decoder", cpus=all_cpus)
             else:
                 par = be.parity_sample()         # first: its CPU value grids feed the baseline's octree / MC legs
                 if par is not None:
                     out["config"]["parity_iou"] = par["min_iou"]
                     out["parity"] = par
-                out["cpu_baseline"] = cpu_baseline.run(args.points, args.resolution0, args.upsampling_steps,
-                                                       int(dec_pts / per), int(gathered[0, F("n_meshes")] / per),
-                                                       scene_grids=getattr(be, "cpu_grids", None),
-                                                       threshold_logit=getattr(be, "cpu_threshold", 0.0))
+                out["cpu_baseline"] = cpu_baseline.run_isolated(
+                    "scene", cpus=all_cpus, points=args.points, resolution0=args.resolution0,
+                    upsampling_steps=args.upsampling_steps, n_queries_per_scene=int(dec_pts / per),
+                    n_prop=int(gathered[0, F("n_meshes")] / per), scene_grids=getattr(be, "cpu_grids", None),
+                    threshold_logit=getattr(be, "cpu_threshold", 0.0))
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
