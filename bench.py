@@ -1092,13 +1092,13 @@ def main(argv=None):
             # workers on one node's cores, MLP legs 10x slower)
             from oracle import cpu_baseline
             if stress:
-                out["cpu_baseline"] = cpu_baseline.run_isolated("decoder", cpus=all_cpus)
+                out["cpu_baseline"] = cpu_baseline.run_best("decoder", cpus=all_cpus)
             else:
                 par = be.parity_sample()         # first: its CPU value grids feed the baseline's octree / MC legs
                 if par is not None:
                     out["config"]["parity_iou"] = par["min_iou"]
                     out["parity"] = par
-                out["cpu_baseline"] = cpu_baseline.run_isolated(
+                out["cpu_baseline"] = cpu_baseline.run_best(
                     "scene", cpus=all_cpus, points=args.points, resolution0=args.resolution0,
                     upsampling_steps=args.upsampling_steps, n_queries_per_scene=int(dec_pts / per),
                     n_prop=int(gathered[0, F("n_meshes")] / per), scene_grids=getattr(be, "cpu_grids", None),

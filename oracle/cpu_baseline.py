@@ -104,6 +104,36 @@ def run_isolated(kind="scene", cpus=None, timeout_s=1800, threads=None, wait_pol
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def sockets(cpus):
+    """number of CPU packages among `cpus` (1 where sysfs does not say)"""
+    ids = set()
+    for c in cpus:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % c) as f:
+                ids.add(int(f.read()))
+        except (OSError, ValueError):
+            pass
+    return max(1, len(ids))
+
+
+def run_best(kind="scene", cpus=None, **kwargs):
+    """bench.py's entry.  The isolated run on every physical core and -- on a multi-socket host -- on ONE socket's
+    cores (`OMP_PROC_BIND=close` fills socket 0 first; measured on the 2 x 64-core MI355X host: the one-socket run
+    is 10-20 % FASTER, the legs' buffers being first-touched by one thread, profiles/r06_cpu_baseline_repeat.txt).
+    The faster one is the baseline (`cores` = the threads it used); the other is kept under `alternatives`."""
+    cpus = sorted(cpus) if cpus else widest_affinity()
+    phys = len(physical_cores(cpus))
+    plans = [phys]
+    n_sock = sockets(cpus)
+    if n_sock > 1 and phys // n_sock >= 1:
+        plans.append(phys // n_sock)
+    outs = [run_isolated(kind, cpus=cpus, threads=t, **dict(kwargs)) for t in plans]
+    best = max(outs, key=lambda o: o["value"])
+    best["alternatives"] = [{"threads": o["cores"], "value": o["value"], "unit": o["unit"],
+                             "stage_s": o.get("stage_s")} for o in outs if o is not best]
+    return best
+
+
 def _probe():
     """where the worker threads of this process may run, after one parallel torch op and one OpenMP oracle call:
     the union of every thread's allowed CPUs (the defect of rounds 4-5 was workers confined to one NUMA node)"""
