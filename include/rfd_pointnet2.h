@@ -156,9 +156,13 @@ int rfd_fps_set_timeout_ms(int ms);
  * 10 at 80 000 points = 32 workgroups).  Geometry sweeps (tools/fps_sweep.py) and tests; results never depend on
  * it.  Returns the previous value, -2 for a value that is not instantiated. */
 int rfd_fps_set_geometry(int points_per_thread);
-/* TEST HOOK, not part of the product path: every round of a multi-workgroup FPS launch also waits for `n` (0..8)
- * exchange units that nobody publishes -- what a workgroup that is never dispatched looks like to the resident ones;
- * the deterministic way into the time-out above.  0 = off.  Returns the previous value. */
+/* The two TEST HOOKS below are compiled out by -DRFD_NO_TEST_HOOKS (`RFD_NO_TEST_HOOKS=1 python -m rfdnet_amd.build`: a
+ * deployment build; tests/test_gpu_fps_abort.py then skips).  The default build carries them so that the library the
+ * GPU tests exercise is the library that ships.
+ * TEST HOOK, not part of the product path: every round of the NEXT multi-workgroup FPS call (one-shot: the call
+ * consumes it) also waits for `n` (0..8) exchange units that nobody publishes -- what a workgroup that is never
+ * dispatched looks like to the resident ones; the deterministic way into the time-out above.  0 = off.  Returns the
+ * previous value. */
 int rfd_fps_test_phantom_units(int n);
 /* TEST HOOK, not part of the product path: occupy all but `leave_free_cus` compute units of the current device with
  * workgroups that each hold a CU's whole LDS, until *release_flag (device memory) becomes non-zero or max_ms (<= 10000)

@@ -39,7 +39,10 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + sources()
+    flags = list(HIPCC_FLAGS)
+    if os.environ.get("RFD_NO_TEST_HOOKS") == "1":     # deployment build: no rfd_test_hold_cus / rfd_fps_test_phantom_units
+        flags.append("-DRFD_NO_TEST_HOOKS")
+    cmd = [hipcc] + flags + ["-o", LIB_PATH] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -166,7 +166,8 @@ RFD_API int rfd_fps_set_geometry(int points_per_thread) {
   return ws->fps_force_ppt.exchange(points_per_thread);
 }
 
-// TEST HOOK: every round of a multi-workgroup FPS launch also waits for `n` exchange units that nobody publishes -- the
+#ifndef RFD_NO_TEST_HOOKS
+// TEST HOOK (one-shot: consumed by the next multi-workgroup FPS call, sampling.hip): every round of a multi-workgroup FPS launch also waits for `n` exchange units that nobody publishes -- the
 // deterministic way to drive a launch into its exchange time-out (what a workgroup that is never dispatched looks like
 // to the resident ones).  0 = off.  Returns the previous value.
 RFD_API int rfd_fps_test_phantom_units(int n) {
@@ -174,5 +175,6 @@ RFD_API int rfd_fps_test_phantom_units(int n) {
   if (rfd_get_workspace(&ws)) return -1;
   return ws->fps_test_phantom.exchange(n < 0 ? 0 : n > 8 ? 8 : n);
 }
+#endif  // RFD_NO_TEST_HOOKS
 
 RFD_API const char *rfd_build_arch(void) { return "gfx950"; }

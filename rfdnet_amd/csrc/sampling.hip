@@ -319,6 +319,7 @@ __global__ void gather_points_grad_kernel(int c, int n, int m,
             grad_out[((size_t)bi * c + l) * m + j]);
 }
 
+#ifndef RFD_NO_TEST_HOOKS
 // Test hook (rfd_test_hold_cus): one 64-thread workgroup per CU, each holding the CU's whole LDS, until *release != 0
 // or max_ticks of wall clock have passed -- so that nothing that needs LDS can be placed beside it.
 constexpr int CU_LDS_BYTES = 160 * 1024;      // gfx950: the whole LDS of a compute unit
@@ -332,6 +333,7 @@ __global__ void hold_cus_kernel(const unsigned *release, u64 max_ticks) {
       __builtin_amdgcn_s_sleep(32);
   }
 }
+#endif  // RFD_NO_TEST_HOOKS
 
 template <int PPT, bool MULTI>
 int launch_fps(int nb, int n, int m, int G, int Gw, int bs_log2, int cpb,
@@ -358,12 +360,19 @@ int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
   const int per_thread = ceil_div(n, FPS_THREADS);
   const int forced = ws->fps_force_ppt.load(std::memory_order_relaxed);
   int ppt, G;
-  if (per_thread <= 16 && !(forced && per_thread > forced)) {  // one workgroup holds the scene
-    G = 1;
-    ppt = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : per_thread <= 8 ? 8 : 16;
-  } else if (forced) {  // rfd_fps_set_geometry: sweeps and tests
+  bool chosen = false;
+  if (forced && per_thread > forced) {  // rfd_fps_set_geometry: sweeps and tests
     ppt = forced;
     G = ceil_div(n, FPS_THREADS * ppt);
+    // a forced size that still leaves ONE workgroup (4096 < n <= 256 ppt) has no single-workgroup instantiation
+    // above 16 points per thread: the hook then does not apply ("results never depend on it"), the automatic
+    // geometry below does
+    chosen = G > 1;
+  }
+  if (chosen) {
+  } else if (per_thread <= 16) {  // one workgroup holds the scene
+    G = 1;
+    ppt = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : per_thread <= 8 ? 8 : 16;
   } else {
     // ~10 points/thread (SA1: 32 exchange units; the sweep towards fewer, fatter units is profiles/r05_fps_sweep.txt);
     // more when the scene would need > 64 workgroups
@@ -380,8 +389,11 @@ int fps_impl(int b, int n, int m, const float *dataset, float *temp, int *idxs,
   const int cpb = ceil_div(n, bs);
   int Gw = G;
   if (G > 1) {
-    const int phantom = ws->fps_test_phantom.load(std::memory_order_relaxed);
+#ifndef RFD_NO_TEST_HOOKS
+    // one-shot: the hook arms the NEXT multi-workgroup call only, a forgotten reset cannot poison a process
+    const int phantom = ws->fps_test_phantom.exchange(0);
     Gw = G + phantom > 64 ? 64 : G + phantom;
+#endif
   }
   const int batches_per_launch = G > 1 ? (FPS_MAX_WG / Gw) : b;
   const u64 timeout_ticks = (u64)ws->fps_timeout_ms.load(std::memory_order_relaxed) * (u64)ws->wall_clock_khz;
@@ -433,6 +445,7 @@ RFD_API int rfd_furthest_point_sampling_gather(int b, int n, int m,
   return fps_impl(b, n, m, dataset, temp, idxs, new_xyz, stream);
 }
 
+#ifndef RFD_NO_TEST_HOOKS
 // Test hook: occupy all but `leave_free_cus` compute units of the current device with workgroups that hold a CU's
 // whole LDS each, until *release_flag (device memory) becomes non-zero or max_ms have passed (hard upper bound: the
 // hook can never hang a device).  A multi-workgroup FPS launched beside it then CANNOT have all its workgroups
@@ -455,6 +468,7 @@ RFD_API int rfd_test_hold_cus(int leave_free_cus, const unsigned *release_flag, 
   if (e != hipSuccess) { rfd_set_error("rfd_test_hold_cus", e); return -(int)e; }
   return n;
 }
+#endif  // RFD_NO_TEST_HOOKS
 
 RFD_API int gather_points_kernel_wrapper(int b, int c, int n, int npoints,
                                          const float *points, const int *idx,

@@ -78,6 +78,9 @@ class ISCNet(nn.Module):
         gen.__dict__ = dict(self.completion.generator.__dict__)
         gen.model, gen.stats, gen.round_hook = comp, {}, None
         gen.__dict__.pop('last_buffers', None)
+        # the round-0 lattice cache is cleared wholesale when full; a view sharing the dict could free tensors another
+        # stream's decode still reads (torch's allocator tracks the allocating stream only): every view its own
+        gen.__dict__.pop('_round0_cache', None)
         comp.generator = gen
         view._modules['completion'] = comp
         return view
@@ -159,6 +162,10 @@ class ISCNet(nn.Module):
         end_points, proposal_features = self.detect(pc)
         ids = self.select_proposals(end_points, selection, pc)
         if ids.shape[1] == 0:                  # nothing survived the selection
+            # detect() may have raised a flag (FPS abort): it is this scene's, read it before returning (reconstruct()
+            # does the same on the other path)
+            from .. import _lib
+            _lib.raise_status(_lib.stream_status_bits())
             return end_points, ids, []
         out = self.reconstruct(end_points, proposal_features, ids, pc, return_grids=return_grids)
         return end_points, ids, out

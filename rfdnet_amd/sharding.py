@@ -207,7 +207,8 @@ PREFLIGHT_FIELDS = ("rank", "device_index", "visible_devices", "pinned_cpus", "a
                     "hw_queues", "free_gib", "library_ok")
 
 
-def preflight(rank, local_rank, world, stub=False, one_device=False, deadline_s=55.0, env=None):
+def preflight(rank, local_rank, world, stub=False, one_device=False, deadline_s=55.0, env=None, allowed_cpus=None,
+              need_gib=8.0):
     """`bench.py --preflight`: can this job start?  Run by EVERY rank (the driver's first `--gpus 8` run is unattended):
       1. local checks any rank can evaluate by itself, BEFORE the rendezvous, so that a mis-sized job fails on every rank
          at once instead of hanging in it: ranks per node vs visible devices, the HIP library loads and is a gfx950 build,
@@ -215,7 +216,8 @@ def preflight(rank, local_rank, world, stub=False, one_device=False, deadline_s=
       2. the rendezvous + ONE all-gather of a small per-rank vector over the job's backend (RCCL over xGMI on GPUs, gloo
          in the CPU tests) -- the collective the benchmark itself ends with -- with the process group's own time-out
          inside the deadline;
-      3. a per-rank report: device index, CPUs pinned / allowed, whether the NUMA node of the pinning is the one HIP's
+      3. a per-rank report: device index, CPUs pinned (now) / allowed (`allowed_cpus`: the mask BEFORE the caller pinned
+         itself, so the report shows whether pinning happened), whether the NUMA node of the pinning is the one HIP's
          PCI address says, GPU_MAX_HW_QUEUES, free HBM.
     Any failure prints ONE line `preflight FAILED [rank r]: <what> -- <what to do>` to stderr and exits non-zero; a
     watchdog ends the process with the same kind of line if anything blocks past `deadline_s`.
@@ -248,8 +250,8 @@ def preflight(rank, local_rank, world, stub=False, one_device=False, deadline_s=
              % (max(n_dev, 1), max(n_dev, 1)))
     dev_index = 0 if one_device else local_rank
     lib_ok, free_gib, numa_ok = 1.0, -1.0, -1.0
-    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else -1
-    pinned = allowed
+    pinned = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else -1
+    allowed = pinned if allowed_cpus is None else int(allowed_cpus)
     device = torch.device("cpu")
     if not stub:
         try:
@@ -266,9 +268,9 @@ def preflight(rank, local_rank, world, stub=False, one_device=False, deadline_s=
                  "run on MI355X (gfx950) -- the kernels are written for that part only")
         free, _ = torch.cuda.mem_get_info(dev_index)
         free_gib = free / 2.0 ** 30
-        if free_gib < 24.0:
-            fail("only %.1f GiB of HBM free on device %d" % (free_gib, dev_index),
-                 "another process holds the GPU (rocm-smi --showpids); the 128^3 sweep keeps ~20 GiB resident")
+        if free_gib < need_gib:              # per config (bench.py HBM_NEED_GIB): a shared GPU is fine for the small ones
+            fail("only %.1f GiB of HBM free on device %d, this configuration needs %.0f" % (free_gib, dev_index, need_gib),
+                 "another process holds the GPU (rocm-smi --showpids), or pick a smaller --config / --in-flight")
         want = numa_cpus_for_bdf(device_bdf(props) or "")
         if want and hasattr(os, "sched_getaffinity"):
             mine = os.sched_getaffinity(0)

@@ -71,10 +71,13 @@ def test_fps_exchange_timeout_aborts_the_whole_launch_and_the_stream_recovers(hi
         assert st & 1, "an exchange that cannot complete must raise status bit 0 (got %d after %.3f s)" % (st, dt)
         assert dt < 1.0, "abort took %.2f s (time-out 40 ms)" % dt
         assert out.cpu().numpy()[0, 0] == 0                 # (whatever follows is garbage or the caller's zero-fill)
+        # the hook is one-shot: the call above consumed it, an un-armed launch is healthy again
+        assert hip.lib().rfd_fps_test_phantom_units(1) == 0
         with torch.cuda.stream(work):
             with pytest.raises(hip.RfdHipError, match="furthest point sampling aborted"):
                 _fps(hip, x, 2048, work, wait=False)        # the same stream, the same exchange region, again
                 hip.stream_status()
+        assert hip.lib().rfd_fps_test_phantom_units(0) == 0
     finally:
         hip.lib().rfd_fps_test_phantom_units(0)
     # the next launches -- same stream and region, forced and default geometry -- are bit-exact again
@@ -180,7 +183,10 @@ def test_fps_geometries_are_bit_exact(hip, oracle, ppt):
 
 
 @pytest.mark.parametrize("b,n,m,ppt", [(3, 20000, 333, 5), (3, 20000, 333, 16), (2, 5001, 1, 8), (2, 9999, 2500, 10),
-                                       (4, 70001, 97, 20), (1, 300000, 64, 32)])
+                                       (4, 70001, 97, 20), (1, 300000, 64, 32),
+                                       # a forced size that leaves ONE workgroup (4096 < n <= 256 ppt) used to
+                                       # fail with hipErrorInvalidValue; the automatic geometry now answers
+                                       (2, 5000, 77, 32), (1, 9000, 50, 40), (1, 16384, 33, 64)])
 def test_forced_geometries_on_odd_shapes_and_batches(hip, oracle, b, n, m, ppt):
     """several scenes per launch (each with its own G exchange units in ONE region), sizes that are no multiple of
     anything, m = 1, duplicates and near-origin points -- against the oracle, geometry forced"""

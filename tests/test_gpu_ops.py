@@ -47,6 +47,50 @@ def test_fps_bit_exact(ext, oracle, hip, b, n, m, dup, origin):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
+def test_fps_nine_scenes_two_launches_default_geometry(ext, oracle, hip):
+    """VERDICT r5 "weak" 10: the multi-launch batch loop of the multi-workgroup kernel (sampling.hip, fps_impl: at
+    80 000 points a launch holds 256 / 32 = 8 scenes, the ninth goes into a second launch on the same exchange region)
+    -- default geometry, nine DIFFERENT scenes, against the oracle"""
+    p = np.stack([synthetic.synthetic_scene(seed=20 + i, n_points=80000)[:, :3] for i in range(9)])
+    ref = oracle.furthest_point_sampling(p, 200)
+    out = ext.furthest_point_sampling(dev(p), 200)
+    hip.device_status()
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    assert len({tuple(r) for r in ref}) == 9
+
+
+def test_fps_300k_automatic_geometry(ext, oracle, hip):
+    """n > 163 840: the launcher's own step to 16 / 32 / 64 points per thread (300 000 -> 32 per thread, 37
+    workgroups), not a forced geometry"""
+    rng = np.random.default_rng(300000)
+    p = scene(rng, 300000, dup=5000, origin=16)[None]
+    ref = oracle.furthest_point_sampling(p, 96)
+    out = ext.furthest_point_sampling(dev(p), 96)
+    hip.device_status()
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n,m", [(37, 50), (512, 515), (5000, 5010)])
+def test_fps_more_samples_than_points(ext, oracle, hip, n, m):
+    """m > n is not rejected by the reference (no shape checks, sampling.cpp:66-87): once every point is taken all
+    distances are 0 and the tree's tie order decides -- single- and multi-workgroup kernels, against the oracle"""
+    rng = np.random.default_rng(n + m)
+    p = scene(rng, n, dup=n // 20, origin=2)[None]
+    ref = oracle.furthest_point_sampling(p, m)
+    out = ext.furthest_point_sampling(dev(p), m)
+    hip.device_status()
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_fps_beyond_the_largest_geometry_raises(ext, hip):
+    """n > 64 workgroups x 256 threads x 64 points = 1 048 576: an error, not a wrong answer"""
+    x = torch.zeros(1, 1048577, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="1048576"):
+        ext.furthest_point_sampling(x, 4)
+    hip.device_status()
+    assert ext.furthest_point_sampling(torch.rand(1, 1048576, 3, device="cuda") + 1, 3).shape == (1, 3)
+
+
 def test_fps_config2_scene_80k(ext, oracle, hip):
     """BASELINE config 2: 80 000 points -> 2048 samples, synthetic ScanNet-like
     scene with duplicated and near-origin points; indices AND the temp scratch."""
@@ -113,6 +157,22 @@ def test_ball_query_bit_exact(ext, oracle, b, n, m, ns, r):
     ref = oracle.ball_query(new, xyz, r, ns)
     out = ext.ball_query(dev(new), dev(xyz), r, ns)
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("m", [341, 342, 682, 683])
+def test_ball_query_dispatch_thresholds_batched(ext, oracle, m):
+    """VERDICT r5 "weak" 10: the launcher picks 1 / 2 / 4 centres per workgroup at m*b = 1024 / 2048
+    (ball_query.hip, query_ball_point_kernel_wrapper).  b = 3 on both sides of both thresholds (m*b = 1023, 1026,
+    2046, 2049), with a ragged last workgroup in the 2- and 4-centre kernels and a centre with no neighbour."""
+    b, n, ns, r = 3, 3000, 24, 0.35
+    rng = np.random.default_rng(m)
+    xyz = np.stack([scene(rng, n, dup=n // 10) for _ in range(b)])
+    new = np.stack([np.concatenate([xyz[i][rng.integers(0, n, m - 1)],
+                                    np.array([[50, 50, 50]], dtype=np.float32)]) for i in range(b)])
+    ref = oracle.ball_query(new, xyz, r, ns)
+    out = ext.ball_query(dev(new), dev(xyz), r, ns)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    assert (ref[:, -1] == 0).all()                         # the empty ball: all zeros (ball_query.cpp:19-21)
 
 
 def test_ball_query_config2_sa1(ext, oracle):
