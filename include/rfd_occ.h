@@ -235,6 +235,28 @@ int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *pac
                    int rows_per_group, const float *R, int ldr, int relu_in, int relu_out,
                    int sa, int sw, float *pool_max, int pool_signed, void *stream);
 
+/* ---- fragment-ordered split activations ("frag rows", csrc/gemm_f16x3.hip) --------------------------------------
+ * Every consumer of an encoder activation rectifies it (layers.py:27,38-46: the in-place ReLU), so a producer can
+ * store relu(x) 2^sa ONCE, already split into f16 (hi, lo) -- the same 4 bytes per element as fp32 -- in the operand
+ * order of the consumer's matrix instruction.  Layout of M rows x C channels (M % 32 == 0, C % 32 == 0):
+ *   [M/32 row blocks][C/32 channel blocks][k step 2][hi, lo][lane 64][8 f16]      (4 KiB per 32 x 32 block)
+ *   row = 32 rb + (lane & 31);  channel = 32 kb + (r & 3) + 8 (r >> 2) + 4 (lane >> 5),  r = 8 kstep + j
+ * A buffer is addressed by the pointer to its first block and the byte stride between row blocks; a channel window is
+ * a pointer offset of 4096 bytes per channel block.  `sa` is a property of the data: producer and consumer agree on it.
+ * rfd_rows_to_frag / rfd_frag_to_rows convert from / to fp32 rows ((hi + lo) 2^-sa is exact).
+ * rfd_gemm_f16x3_frag: C_frag = split(relu(A W^T + bias + gbias[m / rows_per_group]) 2^sa), A given as frag rows;
+ * M % 256 == 0, N % 256 == 0, K % 128 == 0, rows_per_group % 64 == 0 when gbias / pool_max is given; packed_w from
+ * rfd_gemm_pack_w.  C_frag may be NULL with pool_max ([M / rows_per_group][N]: max over the group's rows of the fp32
+ * result -- max(0, .) into a zero-initialised pool, the plain max into a -inf-initialised one with pool_signed).
+ * Replaces, per ResnetBlockFC of the encoder (layers.py:5-48, 340-392), the ReLU + scale + split that every GEMM
+ * re-did on its fp32 input, and the epilogue's transposition through LDS. */
+size_t rfd_frag_bytes(int M, int C);
+int rfd_rows_to_frag(int M, int C, const float *x, int ldx, int relu, int sa, void *out, long rb_stride, void *stream);
+int rfd_frag_to_rows(int M, int C, const void *in, long rb_stride, int sa, float *x, int ldx, void *stream);
+int rfd_gemm_f16x3_frag(int M, int N, int K, const void *A_frag, long a_rb_stride, const void *packed_w,
+                        void *C_frag, long c_rb_stride, const float *bias, const float *gbias,
+                        int rows_per_group, int sa, int sw, float *pool_max, int pool_signed, void *stream);
+
 /* ---- first layer of the skip-propagation point encoder (csrc/pos_embed.hip) ------------
  * fc_pos applied to cat([points, box feature]) * mask (skip_propagation.py:55-66,
  * layers.py:364-366), with the per-proposal share hoisted out by the caller:
@@ -246,6 +268,11 @@ int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *pac
 int rfd_pos_embed(int M, int N, int d, const float *x, int ldx, const float *mask,
                   const float *W, int ldw, const float *bias, const float *group,
                   int rows_per_group, float *out, int ldo, int sa, void *stream);
+/* the same layer written as frag rows (above) of relu(out) 2^sa: out = first block, rb_stride = bytes between row
+ * blocks; M % 32 == 0, N % 32 == 0, rows_per_group % 32 == 0, 1 <= d <= 8 */
+int rfd_pos_embed_frag(int M, int N, int d, const float *x, int ldx, const float *mask,
+                       const float *W, int ldw, const float *bias, const float *group,
+                       int rows_per_group, void *out, long rb_stride, int sa, void *stream);
 
 /* ---- PointNet feature chains of the skip-propagation nets, fused (csrc/pointseg_chain.hip) ----------------
  * models/iscnet/modules/pointseg.py:7-42 (STN3d), :45-79 (STNkd), :82-129 (PointNetEncoder): per point

@@ -63,6 +63,10 @@ SIGNATURES = {
     "rfd_head_pack": [_f, _f, _f, _i, _i, _i, _f, _f],
     "rfd_head_scores": [_i, _i, _f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f],
     "rfd_pos_embed": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _f],
+    "rfd_pos_embed_frag": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, C.c_long, _i, _f],
+    "rfd_rows_to_frag": [_i, _i, _f, _i, _i, _i, _f, C.c_long, _f],
+    "rfd_frag_to_rows": [_i, _i, _f, C.c_long, _i, _f, _i, _f],
+    "rfd_gemm_f16x3_frag": [_i, _i, _i, _f, C.c_long, _f, _f, C.c_long, _f, _f, _i, _i, _i, _f, _i, _f],
 }
 _RESTYPES = {
     "rfd_last_error_string": C.c_char_p,
@@ -71,7 +75,7 @@ _RESTYPES = {
     "rfd_occ_packed_bytes": C.c_size_t,
 }
 _INT_FNS = {"rfd_stream_status": [_f], "rfd_release_stream": [_f], "rfd_stream_status_snapshot": [_f, _f]}
-_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_chain_packed_bytes": [], "rfd_head_packed_bytes": []}
+_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_frag_bytes": [_i, _i], "rfd_chain_packed_bytes": [], "rfd_head_packed_bytes": []}
 
 _lib = None
 

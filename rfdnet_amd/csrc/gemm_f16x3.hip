@@ -93,6 +93,9 @@ struct Args {
   float *pool;                  // [M/rows_per_group][N] running max(0, C) per group, or null (row-owner kernel)
   int pool_signed;              // pool holds the plain max (caller initialises it to -inf) instead of max(0, C)
   unsigned *status;             // device status word (bit 2: an activation left the f16 range)
+  // fragment-ordered split activations (gemm_rowsf_kernel): first 4-KiB block of a 32-row block, stride between row blocks
+  const unsigned char *Af; long af_stride;
+  unsigned char *Cf; long cf_stride;      // Cf may be null (pool only)
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
@@ -577,10 +580,299 @@ __global__ __launch_bounds__(512) void gemm_rows8_kernel(Args g) {
   rows_epilogue<HAS_RES>(g, smem, acc, wave, lane, m0, n0);
 }
 
+
+// ======================================================================================
+// Fragment-ordered split activations ("frag rows"), round 6.
+//
+// The row-owner kernel above reads fp32 rows: lane = row, 32 distinct cache lines per load
+// instruction, and every consumer (two n tiles per GEMM, two GEMMs per block input) rectifies,
+// scales and splits the same activations again on the VALU.  Every consumer of an encoder
+// activation rectifies it (layers.py:27,38-46: the in-place ReLU), so the PRODUCER can store
+// relu(x) 2^sa already split into f16 (hi, lo) -- the same 4 bytes per element -- and store it in
+// the order the consumer's matrix instruction wants its B operand:
+//
+//   block (rb, kb) = rows 32 rb .. +31, channels 32 kb .. +31 = 4 KiB:
+//     [kstep 2][split hi / lo][lane 64][8 f16]
+//     row     = 32 rb + (lane & 31)
+//     channel = 32 kb + (r & 3) + 8 (r >> 2) + 4 (lane >> 5),   r = 8 kstep + j
+//
+// i.e. the channel order inside a block is the ACCUMULATOR order of v_mfma_f32_32x32x16 (a lane
+// holds 16 channels of one row), so a producer's epilogue converts its accumulators in registers
+// and writes four fully coalesced 1-KiB runs per block -- no transpose through LDS -- and the
+// consumer's k loop issues four coalesced 16-byte loads per lane and 32-wide k piece whose results
+// ARE the B fragments: no LDS, no VALU, no partial cache lines.  W is packed in the matching k
+// order (layout 3 of rfd_gemm_pack_w).  A buffer is [M / 32][row-block stride]; a column window
+// is a block offset, so [hidden | input] concatenations stay free.
+constexpr int FRAG_BLOCK_BYTES = 4096;
+
+__device__ __host__ __forceinline__ int frag_channel(int kstep, int half, int j) {
+  const int r = 8 * kstep + j;
+  return (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+
+// layout 3: [N/256][K/32][kstep 2][blk 8][split 2][lane 64][8] f16,
+// n = 256 ntile + 32 blk + (lane & 31), k = 32 piece + frag_channel(kstep, lane >> 5, j)
+__global__ void gemm_pack_frag_kernel(int N, int K, int sw, const float *__restrict__ W,
+                                      _Float16 *__restrict__ packed) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * K * 2;
+  if (e >= total) return;
+  const int j = e & 7;
+  const int lane = (e >> 3) & 63;
+  const int split = (e >> 9) & 1;
+  const int blk = (e >> 10) & 7;
+  const int kstep = (e >> 13) & 1;
+  const size_t rest = e >> 14;
+  const int piece = (int)(rest % (K / RK));
+  const int ntile = (int)(rest / (K / RK));
+  const int n = ntile * RN + blk * 32 + (lane & 31);
+  const int k = piece * RK + frag_channel(kstep, lane >> 5, j);
+  const float w = ldexpf(W[(size_t)n * K + k], sw);
+  const _Float16 hi = (_Float16)w;
+  const _Float16 lo = (_Float16)(w - (float)hi);
+  packed[e] = split == 0 ? hi : lo;
+}
+
+// (hi, lo) words of two scaled, rectified values
+__device__ __forceinline__ void split2(float a0, float a1, unsigned &hw, unsigned &lw) {
+  const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+  const float r0 = a0 - (float)h2[0], r1 = a1 - (float)h2[1];
+  hw = __builtin_bit_cast(unsigned, h2);
+  lw = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+}
+
+// fp32 rows -> frag rows (relu optional; values scaled by 2^sa).  One thread = one lane of one block.
+__global__ __launch_bounds__(256) void rows_to_frag_kernel(int M, int C, const float *__restrict__ x, int ldx,
+                                                          int relu, float a_scale, unsigned char *__restrict__ out,
+                                                          long rb_stride, unsigned *status) {
+  const size_t u = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // block index (rb major)
+  const int lane = threadIdx.x & 63;
+  const int kbs = C / 32;
+  if (u >= (size_t)(M / 32) * kbs) return;
+  const int rb = (int)(u / kbs), kb = (int)(u % kbs);
+  const float *row = x + (size_t)(32 * rb + (lane & 31)) * ldx + 32 * kb + 4 * (lane >> 5);
+  unsigned char *dst = out + (size_t)rb * rb_stride + (size_t)kb * FRAG_BLOCK_BYTES + lane * 16;
+  unsigned amax16 = 0u;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 8 * (2 * s + q));
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        float a0 = v[e] * a_scale, a1 = v[e + 1] * a_scale;
+        if (relu) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
+        split2(a0, a1, hw[2 * q + e / 2], lw[2 * q + e / 2]);
+        amax16 = amax_u16(amax16, hw[2 * q + e / 2], false);
+      }
+    }
+    *reinterpret_cast<u32x4 *>(dst + s * 2048) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<u32x4 *>(dst + s * 2048 + 1024) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+  }
+  flag_overflow(amax16, status);
+}
+
+// frag rows -> fp32 rows: (hi + lo) 2^-sa (exact: 22 significant bits)
+__global__ __launch_bounds__(256) void frag_to_rows_kernel(int M, int C, const unsigned char *__restrict__ in,
+                                                          long rb_stride, float inv_scale, float *__restrict__ x,
+                                                          int ldx) {
+  const size_t u = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int kbs = C / 32;
+  if (u >= (size_t)(M / 32) * kbs) return;
+  const int rb = (int)(u / kbs), kb = (int)(u % kbs);
+  float *row = x + (size_t)(32 * rb + (lane & 31)) * ldx + 32 * kb + 4 * (lane >> 5);
+  const unsigned char *src = in + (size_t)rb * rb_stride + (size_t)kb * FRAG_BLOCK_BYTES + lane * 16;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const half8 hi = *reinterpret_cast<const half8 *>(src + s * 2048);
+    const half8 lo = *reinterpret_cast<const half8 *>(src + s * 2048 + 1024);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ((float)hi[4 * q + e] + (float)lo[4 * q + e]) * inv_scale;
+      *reinterpret_cast<f32x4 *>(row + 8 * (2 * s + q)) = v;
+    }
+  }
+}
+
+// Epilogue of the frag kernel: accumulators -> bias / group bias -> ReLU -> 2^sa -> (hi, lo) -> four 1-KiB runs per
+// 32 x 32 block, straight from the registers.  Lanes of a half-wave read the same bias addresses (broadcast).
+__device__ __forceinline__ void frag_epilogue(const Args &g, const f32x16 (&acc)[8], int rb, int lane, int m0, int n0) {
+  const int half = lane >> 5;
+  const float *bias = g.bias + n0 + 4 * half;
+  const float *gb = g.gbias + (size_t)(m0 / g.rows_per_group) * g.gbias_stride + n0 + 4 * half;
+  unsigned char *dst = g.Cf + (size_t)rb * g.cf_stride + (size_t)(n0 / 32) * FRAG_BLOCK_BYTES + lane * 16;
+  unsigned amax16 = 0u;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    unsigned hw[8], lw[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 cb = *reinterpret_cast<const f32x4 *>(bias + 32 * b + 8 * q) +
+                       *reinterpret_cast<const f32x4 *>(gb + 32 * b + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        float v0 = __builtin_fmaf(acc[b][4 * q + e], g.out_scale, cb[e]);
+        float v1 = __builtin_fmaf(acc[b][4 * q + e + 1], g.out_scale, cb[e + 1]);
+        v0 = (v0 > 0.f ? v0 : 0.f) * g.a_scale;
+        v1 = (v1 > 0.f ? v1 : 0.f) * g.a_scale;
+        split2(v0, v1, hw[2 * q + e / 2], lw[2 * q + e / 2]);
+        amax16 = amax_u16(amax16, hw[2 * q + e / 2], true);
+      }
+    }
+    unsigned char *d = dst + b * FRAG_BLOCK_BYTES;
+    *reinterpret_cast<u32x4 *>(d) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<u32x4 *>(d + 1024) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+    *reinterpret_cast<u32x4 *>(d + 2048) = u32x4{hw[4], hw[5], hw[6], hw[7]};
+    *reinterpret_cast<u32x4 *>(d + 3072) = u32x4{lw[4], lw[5], lw[6], lw[7]};
+  }
+  // cvt_pkrtz saturates at 65504 = 0x7bff: a stored hi word that large means the value left the f16 range
+  flag_overflow(amax16, g.status);
+}
+
+// Row-owner GEMM on frag rows: same tiling as gemm_rows8_kernel (256 x 256 per workgroup, a wave = 32 rows x 256
+// columns, W through the 4-slot LDS ring), but the activation operand arrives as ready B fragments.
+// Vector-memory operations per wave and piece, in issue order:
+//   s = 0: dma, dma, [end] 2 loads (k-step-0 fragments of piece p + 2)
+//   s = 1: dma, dma, [end] 2 loads (k-step-1 fragments of piece p + 2)
+// so the loads a k step consumes were issued exactly one piece and a half-piece earlier with 12 operations behind
+// them: `wait_vm<12>` before each k step's first use; the W transfers for piece p + 1 (issued during piece p - 2)
+// are older still.  Fewer operations issued (tail: no loads) only make the waits more conservative.
+template <bool STORE>
+__global__ __launch_bounds__(512) void gemm_rowsf_kernel(Args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * R_PIECE_BYTES];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int ntiles = g.N / RN;
+  int ntile, mtile;
+  {
+    const int mtiles = g.M / RM;
+    if (mtiles % 8 == 0) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      ntile = j % ntiles;
+      mtile = (j / ntiles) * 8 + xcd;
+    } else {
+      ntile = blockIdx.x % ntiles;
+      mtile = blockIdx.x / ntiles;
+    }
+  }
+  const int rb = mtile * 8 + wave;
+  const int m0 = rb * 32, n0 = ntile * RN;
+  const int np = g.K / RK;
+  const char *wp = reinterpret_cast<const char *>(g.Wp) +
+                   ((size_t)g.N * g.K * 4 + (size_t)ntile * np * (R_PIECE_BYTES / 2)) * 2;
+  const unsigned char *xp = g.Af + (size_t)rb * g.af_stride + lane16;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = f32x16{0.f};
+  u32x4 F[2][4];
+
+  auto load_k0 = [&](int slot) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:1024"
+                 : "=&v"(F[slot][0]), "=&v"(F[slot][1]) : "v"(xp) : "memory");
+  };
+  auto load_k1 = [&](int slot) {
+    asm volatile("global_load_dwordx4 %0, %2, off offset:2048\n\tglobal_load_dwordx4 %1, %2, off offset:3072"
+                 : "=&v"(F[slot][2]), "=&v"(F[slot][3]) : "v"(xp) : "memory");
+  };
+  auto dma = [&](unsigned poff, int slot, int jj) {
+    const char *src = wp + poff + (wave * 4 + jj) * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane16),
+                                     (lds_void *)(smem + slot * R_PIECE_BYTES + (wave * 4 + jj) * 1024), 16, 0, 0);
+  };
+
+  load_k0(0);
+  load_k1(0);
+  xp += FRAG_BLOCK_BYTES;
+  load_k0(1);
+  load_k1(1);
+  xp += FRAG_BLOCK_BYTES;                 // -> piece 2
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dma(p * R_PIECE_BYTES, p, jj);
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  const unsigned wbytes = (unsigned)np * R_PIECE_BYTES;
+  unsigned doff = 3 * R_PIECE_BYTES;
+  for (int p4 = 0; p4 < np; p4 += 4) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int xs = ps & 1;
+      const bool load_next = p4 + ps + 2 < np;
+      const half8 *w = reinterpret_cast<const half8 *>(smem + ps * R_PIECE_BYTES) + lane;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        half8 c[2][2], nx[2][2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          c[o][0] = w[(s * 16 + 2 * o) * 64];
+          c[o][1] = w[(s * 16 + 2 * o + 1) * 64];
+        }
+        const half8 h0 = __builtin_bit_cast(half8, F[xs][2 * s]);
+        const half8 l0 = __builtin_bit_cast(half8, F[xs][2 * s + 1]);
+#pragma unroll
+        for (int bp = 0; bp < 4; ++bp) {
+          if (bp < 3) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+              nx[o][0] = w[(s * 16 + 4 * bp + 4 + 2 * o) * 64];
+              nx[o][1] = w[(s * 16 + 4 * bp + 5 + 2 * o) * 64];
+            }
+          }
+          const int b0 = 2 * bp, b1 = 2 * bp + 1;
+          acc[b0] = mfma(c[0][0], h0, acc[b0]);
+          acc[b1] = mfma(c[1][0], h0, acc[b1]);
+          acc[b0] = mfma(c[0][0], l0, acc[b0]);
+          acc[b1] = mfma(c[1][0], l0, acc[b1]);
+          acc[b0] = mfma(c[0][1], h0, acc[b0]);
+          acc[b1] = mfma(c[1][1], h0, acc[b1]);
+          if (!(bp & 1)) dma(doff, (ps + 3) & 3, 2 * s + (bp >> 1));
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < 4 && bp < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (q == 3 && !(bp & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (bp < 3) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+              c[o][0] = nx[o][0];
+              c[o][1] = nx[o][1];
+            }
+          }
+        }
+        // this k step's fragments are consumed (the matrix instructions above have read them): reload the
+        // registers with the same k step of piece p + 2
+        if (load_next) {
+          if (s == 0) load_k0(xs);
+          else load_k1(xs);
+        }
+        wait_vm<12>();
+      }
+      if (load_next) xp += FRAG_BLOCK_BYTES;
+      doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();    // every wave's W transfers have landed: the ring is free
+  if (STORE) frag_epilogue(g, acc, rb, lane, m0, n0);
+  if (g.pool) pool_epilogue(g, smem, acc, wave, lane, m0, n0);
+}
+
 }  // namespace
 
 // two layouts: the 128 x 128 tile stream, then (for N % 256 == 0, K % 128 == 0) the row-owner stream
-RFD_API size_t rfd_gemm_packed_bytes(int N, int K) { return (size_t)N * K * 2 * sizeof(_Float16) * 2; }
+// three layouts: tile stream, row-owner stream (fp32 rows), row-owner stream in frag k order
+RFD_API size_t rfd_gemm_packed_bytes(int N, int K) { return (size_t)N * K * 2 * sizeof(_Float16) * 3; }
 
 // W [N][K] fp32 (device) -> packed (device).  N % 128 == 0, K % 32 == 0.
 RFD_API int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, void *stream) {
@@ -592,6 +884,9 @@ RFD_API int rfd_gemm_pack_w(int N, int K, int sw, const float *W, void *packed, 
   if (N % RN == 0 && K % 128 == 0) {
     hipLaunchKernelGGL(gemm_pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, N, K, sw, W, (_Float16 *)packed + total);
+    RFD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gemm_pack_frag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, N, K, sw, W, (_Float16 *)packed + 2 * total);
     RFD_CHECK_LAUNCH();
   }
   return 0;
@@ -655,6 +950,82 @@ RFD_API int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const v
     }
     hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, (hipStream_t)stream, g);
   }
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- frag rows (see "Fragment-ordered split activations" above) ------------------------------------------------
+// bytes of a frag buffer of M rows x C channels (M % 32 == 0, C % 32 == 0): [M/32][C/32][4096]
+RFD_API size_t rfd_frag_bytes(int M, int C) { return (size_t)(M / 32) * (C / 32) * FRAG_BLOCK_BYTES; }
+
+// x [M][ldx] fp32 -> frag rows of relu?(x) 2^sa.  out = first block of row block 0, rb_stride = bytes between row blocks.
+RFD_API int rfd_rows_to_frag(int M, int C, const float *x, int ldx, int relu, int sa, void *out, long rb_stride,
+                             void *stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (M % 32 || C % 32 || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || (rb_stride & 15)) {
+    rfd_set_error("rfd_rows_to_frag: M % 32, C % 32, 16-byte aligned rows / blocks", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  RfdWorkspace *ws;
+  int rc = rfd_get_workspace(&ws);
+  if (rc) return rc;
+  const size_t units = (size_t)(M / 32) * (C / 32);
+  hipLaunchKernelGGL(rows_to_frag_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, M, C, x,
+                     ldx, relu, ldexpf(1.f, sa), (unsigned char *)out, rb_stride, rfd_status_word(ws, (hipStream_t)stream));
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+RFD_API int rfd_frag_to_rows(int M, int C, const void *in, long rb_stride, int sa, float *x, int ldx, void *stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (M % 32 || C % 32 || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)in & 15) || (rb_stride & 15)) {
+    rfd_set_error("rfd_frag_to_rows: M % 32, C % 32, 16-byte aligned rows / blocks", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  const size_t units = (size_t)(M / 32) * (C / 32);
+  hipLaunchKernelGGL(frag_to_rows_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, M, C,
+                     (const unsigned char *)in, rb_stride, ldexpf(1.f, -sa), x, ldx);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+// C_frag = split(relu(A W^T + bias + gbias[m / rows_per_group]) 2^sa) with A given as frag rows (already rectified and
+// scaled by 2^sa by ITS producer).  M % 256 == 0, N % 256 == 0, K % 128 == 0, rows_per_group % 64 == 0 when gbias or
+// pool_max is given.  C_frag may be NULL with pool_max (max over the rows of each group of the fp32 result: max(0, .)
+// into a zero-initialised pool, or the plain max into a -inf-initialised one with pool_signed).
+RFD_API int rfd_gemm_f16x3_frag(int M, int N, int K, const void *A_frag, long a_rb_stride, const void *packed_w,
+                                void *C_frag, long c_rb_stride, const float *bias, const float *gbias,
+                                int rows_per_group, int sa, int sw, float *pool_max, int pool_signed, void *stream) {
+  if (M <= 0) return 0;
+  if (!C_frag && !pool_max) {
+    rfd_set_error("rfd_gemm_f16x3_frag: C_frag == NULL without pool_max", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  const int rpg = rows_per_group > 0 ? rows_per_group : 1;
+  if (M % RM || N % RN || K % 128 || N > RFD_ZEROS_FLOATS || ((gbias || pool_max) && rpg % 64) || (a_rb_stride & 15) ||
+      (c_rb_stride & 15) || ((uintptr_t)A_frag & 15) || ((uintptr_t)C_frag & 15) || ((uintptr_t)bias & 15) ||
+      ((uintptr_t)gbias & 15)) {
+    rfd_set_error("rfd_gemm_f16x3_frag: need M % 256, N % 256, K % 128, rows_per_group % 64, 16-byte aligned operands",
+                  hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  RfdWorkspace *ws;
+  int rc = rfd_get_workspace(&ws);
+  if (rc) return rc;
+  Args g;
+  g.A = nullptr; g.lda = 0; g.Wp = (const half8 *)packed_w; g.C = nullptr; g.ldc = 0;
+  g.bias = bias ? bias : ws->zeros;
+  g.gbias = gbias ? gbias : ws->zeros; g.gbias_stride = gbias ? N : 0;
+  g.rows_per_group = (gbias || pool_max) ? rpg : M;      // one group when nothing is per group
+  g.R = nullptr; g.ldr = 0; g.M = M; g.N = N; g.K = K; g.relu_in = 0; g.relu_out = 0;
+  g.a_scale = ldexpf(1.f, sa); g.out_scale = ldexpf(1.f, -(sa + sw));
+  g.pool = pool_max; g.pool_signed = pool_signed;
+  g.status = rfd_status_word(ws, (hipStream_t)stream);
+  g.Af = (const unsigned char *)A_frag; g.af_stride = a_rb_stride;
+  g.Cf = (unsigned char *)C_frag; g.cf_stride = c_rb_stride;
+  const dim3 grid((M / RM) * (N / RN));
+  if (C_frag) hipLaunchKernelGGL((gemm_rowsf_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL((gemm_rowsf_kernel<false>), grid, dim3(512), 0, (hipStream_t)stream, g);
   RFD_CHECK_LAUNCH();
   return 0;
 }

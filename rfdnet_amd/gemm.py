@@ -89,3 +89,83 @@ def lower_scale():
 
 def pool_usable(M, N, K, rows_per_group):
     return M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and rows_per_group % 64 == 0
+
+
+# ---- fragment-ordered split activations ("frag rows", csrc/gemm_f16x3.hip) -----------------------------------------
+# A frag buffer of M rows x C channels is an f16 tensor of shape (M/32, C/32, 2, 2, 64, 8) = [row block][channel block]
+# [k step][hi / lo][lane][8]: relu(x) * 2^sa split into f16 (hi, lo), in the operand order of the consumer's matrix
+# instruction.  A channel window is a slice of dim 1 (row-block stride = stride(0)), so [hidden | input] concatenations
+# are views.  The scale exponent `sa` is a property of the DATA: producer and consumer of a buffer must use the same one
+# (callers capture gemm.SA once per forward pass).
+FRAG_SHAPE = (2, 2, 64, 8)
+
+
+def frag_empty(M, C, device):
+    assert M % 32 == 0 and C % 32 == 0
+    return torch.empty((M // 32, C // 32) + FRAG_SHAPE, dtype=torch.float16, device=device)
+
+
+def _frag_args(f):
+    """(data_ptr, row-block stride in bytes) of a frag tensor or a dim-1 window of one"""
+    assert f.dtype == torch.float16 and f.shape[2:] == FRAG_SHAPE and f.stride()[1:] == (2048, 1024, 512, 8, 1), \
+        "not a frag buffer (or not a plain channel window of one)"
+    return f.data_ptr(), f.stride(0) * 2
+
+
+def frag_usable(M, N, K, rows_per_group=64):
+    """shapes rfd_gemm_f16x3_frag takes"""
+    return M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and rows_per_group % 64 == 0
+
+
+def rows_to_frag(x, sa=None, relu=True, out=None):
+    """x (M,C) fp32 rows (row stride allowed) -> frag buffer of relu?(x) * 2^sa"""
+    M, Cc = x.shape
+    sa = SA if sa is None else sa
+    assert x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1
+    out = frag_empty(M, Cc, x.device) if out is None else out
+    ptr, stride = _frag_args(out)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().rfd_rows_to_frag(M, Cc, x.data_ptr(), x.stride(0), int(relu), int(sa), ptr, stride,
+                                         _lib.current_stream())
+    _lib.check(rc, "rfd_rows_to_frag")
+    return out
+
+
+def frag_to_rows(f, sa=None):
+    """frag buffer (or channel window) -> (M,C) fp32 = (hi + lo) * 2^-sa (exact)"""
+    sa = SA if sa is None else sa
+    M, Cc = f.shape[0] * 32, f.shape[1] * 32
+    x = torch.empty(M, Cc, dtype=torch.float32, device=f.device)
+    ptr, stride = _frag_args(f)
+    with torch.cuda.device(f.device):
+        rc = _lib.lib().rfd_frag_to_rows(M, Cc, ptr, stride, int(sa), x.data_ptr(), Cc, _lib.current_stream())
+    _lib.check(rc, "rfd_frag_to_rows")
+    return x
+
+
+def linear_frag(a, weight, bias=None, gbias=None, rows_per_group=1, out=None, pool=None, store=True,
+                pool_signed=False, sa=None):
+    """split(relu(A @ weight.T + bias + gbias[row // rows_per_group]) * 2^sa) with A given as a frag buffer / window
+    (already rectified and scaled by ITS producer at the same sa).  out: frag buffer / window for the result (allocated
+    when None and store); pool: (M / rows_per_group, N) receives the max over each group's rows of the fp32 result
+    (max(0, .) into zeros; the plain max into -inf with pool_signed).  Returns out (None with store=False)."""
+    M, K = a.shape[0] * 32, a.shape[1] * 32
+    N = weight.shape[0]
+    sa = SA if sa is None else sa
+    assert weight.shape[1] == K and frag_usable(M, N, K, rows_per_group if (gbias is not None or pool is not None) else 64)
+    packed, sw, _ = _packed(weight)
+    if not store:
+        assert pool is not None, "store=False only makes sense with a pool"
+        out = None
+    elif out is None:
+        out = frag_empty(M, N, a.device)
+    aptr, astride = _frag_args(a)
+    cptr, cstride = _frag_args(out) if out is not None else (None, 0)
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().rfd_gemm_f16x3_frag(
+            M, N, K, aptr, astride, packed.data_ptr(), cptr, cstride,
+            bias.data_ptr() if bias is not None else None, gbias.data_ptr() if gbias is not None else None,
+            int(rows_per_group), int(sa), sw, pool.data_ptr() if pool is not None else None, int(pool_signed),
+            _lib.current_stream())
+    _lib.check(rc, "rfd_gemm_f16x3_frag")
+    return out

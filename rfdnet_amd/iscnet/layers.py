@@ -88,24 +88,7 @@ class ResnetPointnet(nn.Module):
         # the first one and re-read as a residual: -0.5 GB of traffic per block at M = 262 144 and
         # no residual epilogue.  The max-pool over a proposal's points (+ the ReLU every consumer
         # applies to it) is fused into the second GEMM's epilogue; the last block is only pooled.
-        def weights(i):
-            blk = getattr(self, 'block_%d' % i)
-            key = (blk.fc_0.weight._version, blk.fc_1.weight._version, blk.shortcut.weight._version,
-                   blk.fc_0.weight.data_ptr())
-            c = self.__dict__.setdefault('_stack_cache', {})
-            if c.get(i, (None,))[0] != key:
-                from .. import _lib
-                with _lib.BUILD_LOCK:      # shared across host threads: built once, published before it is stored
-                    if c.get(i, (None,))[0] != key:
-                        w0, ws = blk.fc_0.weight.detach(), blk.shortcut.weight.detach()
-                        wide = i == 0                                   # block 0: all 2h input columns are per-point
-                        first = (w0 if wide else w0[:, :h]).contiguous()
-                        second = torch.cat([blk.fc_1.weight.detach(), ws if wide else ws[:, :h]], 1).contiguous()
-                        entry = (key, first, second, None if wide else w0[:, h:].contiguous(),
-                                 None if wide else ws[:, h:].contiguous())
-                        _lib.publish(second.device)
-                        c[i] = entry
-            return (blk,) + c[i][1:]
+        weights = self._block_weights
 
         fuse_pool = gemm.pool_usable(M, h, 2 * h, T)
         cat = self.__dict__.pop('_cat0', None)
@@ -129,6 +112,74 @@ class ResnetPointnet(nn.Module):
                         store=nxt is not None)
             if pooled is None:
                 pooled = torch.relu(self.pool(nxt[:, h:].reshape(B, T, h), dim=1))
+            cat = nxt
+        return self.fc_c(pooled)                                             # = fc_c(relu(max over the points))
+
+    def _block_weights(self, i):
+        """Block i as TWO GEMMs over one buffer [hidden | block input]: (blk, W_first, W_second, W0_pool, Ws_pool) with
+        W_first = fc_0 on the per-point columns, W_second = [fc_1 | shortcut on the per-point columns], and the two
+        pooled-half matrices (None for block 0, whose 2h input columns are all per-point).  Built once per parameter
+        version, shared by the host threads."""
+        h = self.block_0.size_h
+        blk = getattr(self, 'block_%d' % i)
+        key = (blk.fc_0.weight._version, blk.fc_1.weight._version, blk.shortcut.weight._version,
+               blk.fc_0.weight.data_ptr())
+        c = self.__dict__.setdefault('_stack_cache', {})
+        if c.get(i, (None,))[0] != key:
+            from .. import _lib
+            with _lib.BUILD_LOCK:      # shared across host threads: built once, published before it is stored
+                if c.get(i, (None,))[0] != key:
+                    w0, ws = blk.fc_0.weight.detach(), blk.shortcut.weight.detach()
+                    wide = i == 0                                   # block 0: all 2h input columns are per-point
+                    first = (w0 if wide else w0[:, :h]).contiguous()
+                    second = torch.cat([blk.fc_1.weight.detach(), ws if wide else ws[:, :h]], 1).contiguous()
+                    entry = (key, first, second, None if wide else w0[:, h:].contiguous(),
+                             None if wide else ws[:, h:].contiguous())
+                    _lib.publish(second.device)
+                    c[i] = entry
+        return (blk,) + c[i][1:]
+
+    def frag_usable(self, B, T):
+        """can forward_frag run this shape (B proposals x T points)?"""
+        from .. import gemm
+        h = self.block_0.size_h
+        return gemm.frag_usable(B * T, h, h, T) and h % 128 == 0
+
+    def frag_input_buffer(self, B, T, device):
+        """Block 0's [hidden | input] buffer in the frag-rows layout (gemm.frag_empty) and the channel window fc_pos
+        writes (pos_embed.pos_embed_frag): -> (buffer, window)."""
+        from .. import gemm
+        h = self.block_0.size_h
+        cat = gemm.frag_empty(B * T, 3 * h, device)
+        return cat, cat[:, h // 32:]
+
+    def forward_frag(self, cat, B, T, sa):
+        """forward_factored() on fragment-ordered split activations (round 6): every activation of the encoder is
+        stored ONCE as relu(x) 2^sa split into f16 (hi, lo) in the operand order of the consumer's matrix instruction
+        (legal because every consumer rectifies: the in-place ReLU of layers.py:27,38-46), so no GEMM re-does the
+        ReLU / scale / split of its input on the VALU (it used to happen four times per block input: two n tiles x two
+        GEMMs), every load is a full 1-KiB run, and no epilogue transposes through LDS.  Same two GEMMs per block,
+        same factoring of the pooled half, same fused max-pool.  `cat` = frag_input_buffer()[0] with fc_pos already
+        written into its window at scale 2^sa."""
+        import torch.nn.functional as F
+        from .. import gemm
+        h = self.block_0.size_h
+        hb = h // 32
+        M = B * T
+        pooled = None
+        for i in range(5):
+            blk, w_first, w_second, w0_pool, ws_pool = self._block_weights(i)
+            g0 = gs = None
+            if i:
+                g0 = F.linear(pooled, w0_pool, blk.fc_0.bias)                # once per proposal
+                gs = F.linear(pooled, ws_pool, blk.fc_1.bias)
+            gemm.linear_frag(cat[:, hb:], w_first, bias=None if i else blk.fc_0.bias, gbias=g0, rows_per_group=T,
+                             out=cat[:, :hb], sa=sa)
+            last = i == 4
+            nxt = None if last else gemm.frag_empty(M, 2 * h, cat.device)
+            pooled = torch.zeros(B, h, device=cat.device, dtype=torch.float32)
+            gemm.linear_frag(cat, w_second, bias=None if i else blk.fc_1.bias, gbias=gs, rows_per_group=T,
+                             out=None if last else nxt[:, hb:], pool=pooled, store=not last, sa=sa)
             cat = nxt
         return self.fc_c(pooled)                                             # = fc_c(relu(max over the points))
 

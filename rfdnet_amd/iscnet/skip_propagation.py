@@ -53,6 +53,15 @@ class SkipPropagation(nn.Module):
         w = enc.fc_pos.weight
         group = F.linear(box, w[:, d:])                                          # (B*K,2h): once per proposal
         rows = inp.reshape(B * K * P, d)
+        if enc.frag_usable(B * K, P) and pos_embed.frag_usable(rows, w, B * K * P, P):
+            # the encoder on fragment-ordered split activations: fc_pos writes block 0's input already rectified,
+            # scaled and split (the scale exponent is captured ONCE: another scene in flight may lower gemm.SA)
+            from .. import gemm
+            sa = gemm.SA
+            cat, window = enc.frag_input_buffer(B * K, P, rows.device)
+            pos_embed.pos_embed_frag(rows, maskf.view(-1), w, enc.fc_pos.bias, group, P, window, sa)
+            codes = enc.forward_frag(cat, B * K, P, sa)
+            return codes.view(B, K, -1).transpose(1, 2)
         pos = enc.input_buffer(B * K, P, rows.device)                            # (B*K*P,2h) window of block 0's buffer
         if pos_embed.usable(rows, w, pos):
             pos_embed.pos_embed(rows, maskf.view(-1), w, enc.fc_pos.bias, group, P, pos)

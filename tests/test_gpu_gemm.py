@@ -364,3 +364,148 @@ def test_scene_survives_a_gemm_range_flag(hip):
         hip.device_status()
     finally:
         gemm.SA = 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fragment-ordered split activations (round 6): rfd_rows_to_frag / rfd_frag_to_rows / rfd_gemm_f16x3_frag /
+# rfd_pos_embed_frag, and the encoder on top of them
+
+
+def test_frag_rows_round_trip_and_layout(hip):
+    """(hi + lo) 2^-sa reproduces relu(x) to the split's 2^-21, a re-split is bit-identical, and the layout is the one
+    include/rfd_occ.h documents (checked element by element against index arithmetic on the host)"""
+    from rfdnet_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, Cc, sa = 96, 160, 4
+    wide = torch.randn(M, Cc + 32, device="cuda", generator=g) * 3
+    x = wide[:, 32:]                                                 # strided rows
+    f = gemm.rows_to_frag(x, sa=sa)
+    back = gemm.frag_to_rows(f, sa=sa)
+    want = torch.relu(x)
+    assert (back - want).abs().max().item() <= 2.0 ** -21 * want.abs().max().item()
+    assert torch.equal(gemm.rows_to_frag(back, sa=sa), f)           # relu(relu(x)) re-splits to the same bits
+    # layout: [rb][kb][kstep][split][lane][j] -> row 32 rb + (lane & 31), channel 32 kb + (r&3) + 8 (r>>2) + 4 (lane>>5)
+    fh = f.float().cpu().numpy()                                     # (3, 5, 2, 2, 64, 8)
+    val = (fh[:, :, :, 0] + fh[:, :, :, 1]) * 2.0 ** -sa            # (rb, kb, kstep, lane, j)
+    w = want.cpu().numpy()
+    rb, kb, ks, lane, j = np.meshgrid(np.arange(3), np.arange(5), np.arange(2), np.arange(64), np.arange(8), indexing="ij")
+    r = 8 * ks + j
+    rows = 32 * rb + (lane & 31)
+    chans = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    np.testing.assert_allclose(val, w[rows, chans], rtol=2.0 ** -20, atol=1e-7)
+    # un-rectified conversion keeps the sign
+    assert (gemm.frag_to_rows(gemm.rows_to_frag(x, sa=sa, relu=False), sa=sa) - x).abs().max().item() <= 2.0 ** -20 * 16
+
+
+@pytest.mark.parametrize("M,N,K,T", [(256, 256, 128, 64), (512, 512, 384, 128), (2048, 512, 1024, 1024)])
+def test_gemm_frag_matches_fp64_reference(hip, M, N, K, T):
+    """rfd_gemm_f16x3_frag against fp64 on the values the frag input REALLY holds: stored output, fused pool,
+    pool-only launch, channel windows on both sides -- fp32-class bounds, as for the fp32-rows kernels"""
+    from rfdnet_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    sa = gemm.SA
+    x = torch.randn(M, K, device="cuda", generator=g) * 2.0
+    w = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / np.sqrt(K)
+    bias = torch.randn(N, device="cuda", generator=g)
+    gb = torch.randn(M // T, N, device="cuda", generator=g)
+    # A = a channel window of a wider frag buffer ([junk | A]); C = a window of another one
+    abuf = gemm.frag_empty(M, K + 64, "cuda")
+    abuf.view(torch.int16).fill_(0x7c00)                              # f16 inf: any read outside the window poisons
+    gemm.rows_to_frag(x, sa=sa, out=abuf[:, 2:])
+    a = abuf[:, 2:]
+    cbuf = gemm.frag_empty(M, N + 32, "cuda")
+    cbuf.view(torch.int16).fill_(0x7c00)
+    pool = torch.zeros(M // T, N, device="cuda")
+    out = gemm.linear_frag(a, w, bias=bias, gbias=gb, rows_per_group=T, out=cbuf[:, 1:], pool=pool, sa=sa)
+    hip.device_status()
+    r = ref(gemm.frag_to_rows(a, sa=sa), w, bias, gb, T, None, False, True)          # relu(A W^T + b + gb), fp64
+    y = gemm.frag_to_rows(out, sa=sa)
+    scale = max(1.0, r.abs().max().item())
+    assert (y.double() - r).abs().max().item() < 2e-5 * scale
+    assert (cbuf[:, 0].view(torch.int16) == 0x7c00).all()            # the neighbouring channel block is untouched
+    rp = r.view(M // T, T, N).max(1)[0]
+    assert (pool.double() - rp).abs().max().item() < 2e-5 * scale
+    # pool only, signed: the plain max of the un-rectified product
+    pool2 = torch.full((M // T, N), float("-inf"), device="cuda")
+    assert gemm.linear_frag(a, w, bias=bias, gbias=gb, rows_per_group=T, pool=pool2, pool_signed=True, store=False,
+                            sa=sa) is None
+    ru = ref(gemm.frag_to_rows(a, sa=sa), w, bias, gb, T, None, False, False).view(M // T, T, N).max(1)[0]
+    assert (pool2.double() - ru).abs().max().item() < 2e-5 * scale
+    # no bias, no group bias, no pool
+    y0 = gemm.frag_to_rows(gemm.linear_frag(a, w, sa=sa), sa=sa)
+    r0 = ref(gemm.frag_to_rows(a, sa=sa), w, None, None, 1, None, False, True)
+    assert (y0.double() - r0).abs().max().item() < 2e-5 * scale
+    hip.device_status()
+
+
+def test_gemm_frag_flags_the_f16_range(hip):
+    """an OUTPUT beyond 65504 / 2^sa cannot be split for the next layer: status bit 2, as the fp32-rows kernels do"""
+    from rfdnet_amd import gemm
+    sa = gemm.SA
+    M, N, K = 256, 256, 128
+    x = torch.full((M, K), 1.0, device="cuda")
+    w = torch.full((N, K), 0.25, device="cuda")
+    a = gemm.rows_to_frag(x, sa=sa)
+    gemm.linear_frag(a, w, sa=sa)
+    hip.device_status()
+    big = torch.full((N,), 65504.0 / 2 ** sa, device="cuda")
+    gemm.linear_frag(a, w, bias=big, sa=sa)
+    with pytest.raises(hip.RfdHipError):
+        hip.device_status()
+    with pytest.raises(hip.RfdHipError):                             # and rows_to_frag itself
+        gemm.rows_to_frag(torch.full((32, 32), 70000.0 / 2 ** sa, device="cuda"), sa=sa)
+        hip.device_status()
+    hip.device_status()
+
+
+@pytest.mark.parametrize("d", [4, 7])
+def test_pos_embed_frag_matches_pos_embed(hip, d):
+    """the frag-rows fc_pos holds exactly split(relu(fp32 fc_pos) 2^sa)"""
+    from rfdnet_amd import gemm, pos_embed
+    g = torch.Generator(device="cuda").manual_seed(d)
+    P, K, N = 1024, 6, 1024
+    M = P * K
+    x = torch.randn(M, d, device="cuda", generator=g)
+    mask = (torch.rand(M, device="cuda", generator=g) > 0.3).float()
+    W = torch.randn(N, d + 128, device="cuda", generator=g) * 0.3
+    bias = torch.randn(N, device="cuda", generator=g)
+    group = torch.randn(K, N, device="cuda", generator=g)
+    plain = torch.empty(M, N, device="cuda")
+    pos_embed.pos_embed(x, mask, W, bias, group, P, plain)
+    cat = gemm.frag_empty(M, N + 512, "cuda")
+    pos_embed.pos_embed_frag(x, mask, W, bias, group, P, cat[:, 16:], gemm.SA)
+    hip.device_status()
+    assert torch.equal(cat[:, 16:], gemm.rows_to_frag(plain, sa=gemm.SA))            # bit for bit
+
+
+def test_encoder_on_frag_rows_matches_the_module(hip):
+    """ResnetPointnet.forward_frag (the round-6 path of the headline) against the module's own fp32 forward() and the
+    fp32-rows factored path, on the encoder's real widths at a small proposal count"""
+    from rfdnet_amd import gemm, pos_embed
+    from rfdnet_amd.iscnet.layers import ResnetPointnet
+    torch.manual_seed(0)
+    enc = ResnetPointnet(c_dim=512, dim=132, hidden_dim=512)
+    synthetic.load_seeded(enc, seed=5)
+    enc = enc.cuda().eval()
+    B, T, d = 4, 1024, 4
+    g = torch.Generator(device="cuda").manual_seed(9)
+    pts = torch.randn(B * T, d, device="cuda", generator=g)
+    mask = (torch.rand(B * T, device="cuda", generator=g) > 0.2).float()
+    box = torch.randn(B, 128, device="cuda", generator=g)
+    w = enc.fc_pos.weight
+    with torch.no_grad():
+        group = torch.nn.functional.linear(box, w[:, d:])
+        full = torch.cat([pts.view(B, T, d), box[:, None].expand(B, T, 128)], 2) * mask.view(B, T, 1)
+        want = enc(full)                                             # the reference composition, fp32
+        assert enc.frag_usable(B, T)
+        sa = gemm.SA
+        cat, window = enc.frag_input_buffer(B, T, "cuda")
+        pos_embed.pos_embed_frag(pts, mask, w, enc.fc_pos.bias, group, T, window, sa)
+        got = enc.forward_frag(cat, B, T, sa)
+        pos = enc.input_buffer(B, T, "cuda")
+        pos_embed.pos_embed(pts, mask, w, enc.fc_pos.bias, group, T, pos)
+        rows = enc.forward_factored(pos.view(B, T, -1))
+    hip.device_status()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, scale), (got - want).abs().max().item()
+    assert (got - rows).abs().max().item() < 2e-5 * max(1.0, scale), (got - rows).abs().max().item()
