@@ -96,6 +96,10 @@ struct Args {
   // fragment-ordered split activations (gemm_rowsf_kernel): first 4-KiB block of a 32-row block, stride between row blocks
   const unsigned char *Af; long af_stride;
   unsigned char *Cf; long cf_stride;      // Cf may be null (pool only)
+  const float *zeros;                     // RFD_ZEROS_FLOATS zeros (the frag kernel's pool epilogue: bias already in the accumulators)
+  // frag kernel: the two additive vectors folded into the accumulator start (zeros when absent); a stride is the
+  // distance between groups (0 for a plain bias)
+  const float *cb1, *cb2; int cb1_stride, cb2_stride;
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Args g) {
@@ -698,30 +702,21 @@ __global__ __launch_bounds__(256) void frag_to_rows_kernel(int M, int C, const u
   }
 }
 
-// Epilogue of the frag kernel: accumulators -> bias / group bias -> ReLU -> 2^sa -> (hi, lo) -> four 1-KiB runs per
-// 32 x 32 block, straight from the registers.  Lanes of a half-wave read the same bias addresses (broadcast).
-__device__ __forceinline__ void frag_epilogue(const Args &g, const f32x16 (&acc)[8], int rb, int lane, int m0, int n0) {
-  const int half = lane >> 5;
-  const float *bias = g.bias + n0 + 4 * half;
-  const float *gb = g.gbias + (size_t)(m0 / g.rows_per_group) * g.gbias_stride + n0 + 4 * half;
+// Epilogue of the frag kernel.  bias + group bias are already IN the accumulators (gemm_rowsf_kernel starts them at
+// (bias + gbias) 2^(sa+sw)), so an element is relu(acc) 2^-sw -> (hi, lo) -> four 1-KiB runs per 32 x 32 block, straight
+// from the registers: no loads, no LDS.
+__device__ __forceinline__ void frag_epilogue(const Args &g, const f32x16 (&acc)[8], int rb, int lane, int n0) {
   unsigned char *dst = g.Cf + (size_t)rb * g.cf_stride + (size_t)(n0 / 32) * FRAG_BLOCK_BYTES + lane * 16;
+  const float post = g.out_scale * g.a_scale;                 // 2^-sw
   unsigned amax16 = 0u;
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
     unsigned hw[8], lw[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 cb = *reinterpret_cast<const f32x4 *>(bias + 32 * b + 8 * q) +
-                       *reinterpret_cast<const f32x4 *>(gb + 32 * b + 8 * q);
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        float v0 = __builtin_fmaf(acc[b][4 * q + e], g.out_scale, cb[e]);
-        float v1 = __builtin_fmaf(acc[b][4 * q + e + 1], g.out_scale, cb[e + 1]);
-        v0 = (v0 > 0.f ? v0 : 0.f) * g.a_scale;
-        v1 = (v1 > 0.f ? v1 : 0.f) * g.a_scale;
-        split2(v0, v1, hw[2 * q + e / 2], lw[2 * q + e / 2]);
-        amax16 = amax_u16(amax16, hw[2 * q + e / 2], true);
-      }
+    for (int w = 0; w < 8; ++w) {
+      const float a0 = acc[b][2 * w], a1 = acc[b][2 * w + 1];
+      split2((a0 > 0.f ? a0 : 0.f) * post, (a1 > 0.f ? a1 : 0.f) * post, hw[w], lw[w]);
+      amax16 = amax_u16(amax16, hw[w], true);
     }
     unsigned char *d = dst + b * FRAG_BLOCK_BYTES;
     *reinterpret_cast<u32x4 *>(d) = u32x4{hw[0], hw[1], hw[2], hw[3]};
@@ -733,44 +728,72 @@ __device__ __forceinline__ void frag_epilogue(const Args &g, const f32x16 (&acc)
   flag_overflow(amax16, g.status);
 }
 
-// Row-owner GEMM on frag rows: same tiling as gemm_rows8_kernel (256 x 256 per workgroup, a wave = 32 rows x 256
-// columns, W through the 4-slot LDS ring), but the activation operand arrives as ready B fragments.
-// Vector-memory operations per wave and piece, in issue order:
-//   s = 0: dma, dma, [end] 2 loads (k-step-0 fragments of piece p + 2)
-//   s = 1: dma, dma, [end] 2 loads (k-step-1 fragments of piece p + 2)
-// so the loads a k step consumes were issued exactly one piece and a half-piece earlier with 12 operations behind
-// them: `wait_vm<12>` before each k step's first use; the W transfers for piece p + 1 (issued during piece p - 2)
-// are older still.  Fewer operations issued (tail: no loads) only make the waits more conservative.
+// Row-owner GEMM on frag rows, PERSISTENT: one workgroup per CU walks its list of 256 x 256 tiles (same n tile, so the
+// same W stream, for all of them) and the operand streams never stop at a tile boundary -- the W ring keeps rolling
+// (piece np of a tile IS piece 0 of the next: the transfer offset wraps) and the activation loads switch to the next
+// tile's row block two pieces before the end.  Between two tiles only the epilogue runs (accumulators -> split -> four
+// 1-KiB runs per block; pool), while the next tile's first pieces are already landing.  Measured on the one-tile-per-
+// launch version of this kernel (tools/ab/r06_sessions.md): per 58-us tile the prologue fetch (x 2 pieces + W 3 pieces,
+// ~4-5 us exposed), the useless wrap-around transfers at the end (~3 us at the LDS-DMA rate) and the workgroup
+// hand-over cost more than the epilogue's arithmetic.
+//
+// Same tiling as gemm_rows8_kernel (a wave = 32 rows x 256 columns, W through the 4-slot LDS ring), but the activation
+// operand arrives as ready B fragments.  Vector-memory LOADS per wave and piece, in issue order:
+//   k step 0: dma, dma, [end] 2 loads (k-step-0 fragments of piece p + 2)
+//   k step 1: dma, dma, [end] 2 loads (k-step-1 fragments of piece p + 2)
+// always issued (the last tile of a workgroup re-reads its own first pieces: the pattern is what the waits count on).
+// vmcnt retires loads in order, so `s_waitcnt vmcnt(N)` proves a load complete iff at least N loads were issued after
+// it (stores in between only make the wait longer).  The fragments a k step consumes were issued a piece and a half
+// earlier with exactly 12 loads behind them -> wait_vm<12> at the end of every k step; the W transfers of piece p + 1
+// (issued during piece p - 2) have 14 behind them at the end of k step 0 of piece p, before the piece barrier.
 template <bool STORE>
 __global__ __launch_bounds__(512) void gemm_rowsf_kernel(Args g) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * R_PIECE_BYTES];
+  // ring (4 x 32 KiB) | per wave: the next tile's accumulator start values (8 x 1 KiB) | pool_epilogue's cross-wave
+  // scratch (8 KiB; the ring is live during the epilogue).  ONE object: with separate __shared__ arrays the compiler
+  // could no longer tell the ring's LDS-DMA writes from the reads and put `s_waitcnt vmcnt(0)` in front of every
+  // ds_read of the loop
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * R_PIECE_BYTES + 16384];
+  float (*cbs)[256] = reinterpret_cast<float (*)[256]>(smem + 4 * R_PIECE_BYTES);
+  float *red = reinterpret_cast<float *>(smem + 4 * R_PIECE_BYTES + 8192);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const unsigned lane16 = (unsigned)lane * 16u;
-  const int ntiles = g.N / RN;
-  int ntile, mtile;
+  const int ntiles = g.N / RN, mtiles = g.M / RM;
+  // tile list of this workgroup: m tile (k0 + i kstep) mul + add, i = 0 .. n_my - 1, fixed n tile.  With 8 | m tiles
+  // and (8 n tiles) | workgroups, the n tiles of one m tile run at the same time on ONE XCD (workgroups are dealt
+  // round-robin to the XCDs; each has its own L2: the activation tile comes from HBM once).
+  int ntile, k0, kstep, mul, add, kend;
   {
-    const int mtiles = g.M / RM;
-    if (mtiles % 8 == 0) {
-      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nwg = gridDim.x, w = blockIdx.x;
+    if (mtiles % 8 == 0 && nwg % (8 * ntiles) == 0) {
+      const int j = w >> 3;
       ntile = j % ntiles;
-      mtile = (j / ntiles) * 8 + xcd;
-    } else {
-      ntile = blockIdx.x % ntiles;
-      mtile = blockIdx.x / ntiles;
+      k0 = j / ntiles;
+      kstep = (nwg >> 3) / ntiles;
+      mul = 8;
+      add = w & 7;
+      kend = mtiles >> 3;
+    } else {                                  // the launcher makes the workgroup count a multiple of n tiles
+      ntile = w % ntiles;
+      k0 = w / ntiles;
+      kstep = nwg / ntiles;
+      mul = 1;
+      add = 0;
+      kend = mtiles;
     }
   }
-  const int rb = mtile * 8 + wave;
-  const int m0 = rb * 32, n0 = ntile * RN;
+  if (k0 >= kend) return;
+  const int n0 = ntile * RN;
   const int np = g.K / RK;
   const char *wp = reinterpret_cast<const char *>(g.Wp) +
                    ((size_t)g.N * g.K * 4 + (size_t)ntile * np * (R_PIECE_BYTES / 2)) * 2;
-  const unsigned char *xp = g.Af + (size_t)rb * g.af_stride + lane16;
+  const int half = lane >> 5;
+  const float pre = 1.f / g.out_scale;
 
   f32x16 acc[8];
-#pragma unroll
-  for (int b = 0; b < 8; ++b) acc[b] = f32x16{0.f};
   u32x4 F[2][4];
+  f32x4 cbv[2];
+  const unsigned char *xp;
 
   auto load_k0 = [&](int slot) {
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:1024"
@@ -785,7 +808,36 @@ __global__ __launch_bounds__(512) void gemm_rowsf_kernel(Args g) {
     __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane16),
                                      (lds_void *)(smem + slot * R_PIECE_BYTES + (wave * 4 + jj) * 1024), 16, 0, 0);
   };
+  // the additive vectors of a tile's group, 4 channels per lane (256 per wave), as two opaque loads
+  auto load_cb = [&](int rb) {
+    const size_t grp = (size_t)((rb * 32) / g.rows_per_group);
+    const float *v1 = g.cb1 + grp * g.cb1_stride + n0 + 4 * lane;
+    const float *v2 = g.cb2 + grp * g.cb2_stride + n0 + 4 * lane;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
+                 : "=&v"(cbv[0]), "=&v"(cbv[1]) : "v"(v1), "v"(v2) : "memory");
+  };
+  // ... summed, scaled to the accumulator's units ((bias + gbias) 2^(sa+sw)) and parked in this wave's LDS row
+  auto park_cb = [&]() {
+    // the loads are opaque to the compiler: without this (volatile asm statements keep their order, so it stays behind
+    // the s_waitcnt) the add below may be scheduled ABOVE the wait and read registers the data has not reached yet
+    asm volatile("" : "+v"(cbv[0]), "+v"(cbv[1]));
+    f32x4 v = (cbv[0] + cbv[1]) * pre;
+    *reinterpret_cast<f32x4 *>(&cbs[wave][4 * lane]) = v;
+  };
+  // accumulators <- parked values: lane (row, half) holds channels 8 q + 4 half .. + 3 of block b
+  auto start_acc = [&]() {
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(&cbs[wave][32 * b + 8 * q + 4 * half]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[b][4 * q + e] = v[e];
+      }
+  };
 
+  int rb = (k0 * mul + add) * 8 + wave;
+  xp = g.Af + (size_t)rb * g.af_stride + lane16;
   load_k0(0);
   load_k1(0);
   xp += FRAG_BLOCK_BYTES;
@@ -796,76 +848,118 @@ __global__ __launch_bounds__(512) void gemm_rowsf_kernel(Args g) {
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) dma(p * R_PIECE_BYTES, p, jj);
+  load_cb(rb);
   wait_vm<0>();
+  park_cb();
+  start_acc();
   __builtin_amdgcn_s_barrier();
 
+  // W fragments of the FIRST block pair of a k step are fetched one k step ahead (in the last block pair's slot of the
+  // previous k step), so no k step starts by waiting for LDS; across pieces that needs the piece barrier BEFORE the
+  // last block pair of k step 1 -- legal: by then a wave has issued (and, after lgkmcnt(0), completed) every read of
+  // this piece's slot, and the transfers of piece p + 1 were waited for at the end of k step 0.
+  half8 c[2][2];
+  {
+    const half8 *w0 = reinterpret_cast<const half8 *>(smem) + lane;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      c[o][0] = w0[(2 * o) * 64];
+      c[o][1] = w0[(2 * o + 1) * 64];
+    }
+  }
   const unsigned wbytes = (unsigned)np * R_PIECE_BYTES;
   unsigned doff = 3 * R_PIECE_BYTES;
-  for (int p4 = 0; p4 < np; p4 += 4) {
+  for (int k = k0; k < kend; k += kstep) {
+    const int m0 = rb * 32;
+    // the row block whose first pieces the END of this tile's loop fetches (the last tile re-reads its own)
+    const int rb_next = k + kstep < kend ? ((k + kstep) * mul + add) * 8 + wave : rb;
+    const unsigned char *next_base = g.Af + (size_t)rb_next * g.af_stride + lane16;
+    for (int p4 = 0; p4 < np; p4 += 4) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int xs = ps & 1;
-      const bool load_next = p4 + ps + 2 < np;
-      const half8 *w = reinterpret_cast<const half8 *>(smem + ps * R_PIECE_BYTES) + lane;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        half8 c[2][2], nx[2][2];
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-          c[o][0] = w[(s * 16 + 2 * o) * 64];
-          c[o][1] = w[(s * 16 + 2 * o + 1) * 64];
+      for (int ps = 0; ps < 4; ++ps) {
+        const int xs = ps & 1;
+        const half8 *w = reinterpret_cast<const half8 *>(smem + ps * R_PIECE_BYTES) + lane;
+        const half8 *wn = reinterpret_cast<const half8 *>(smem + ((ps + 1) & 3) * R_PIECE_BYTES) + lane;
+        if (p4 == 0) {
+          // the next tile's start values: fetched with piece 0 (16 loads will follow by the end of piece 1), parked in
+          // LDS at piece 2 -- after this tile's own start values were read (start_acc above / at the end of the loop)
+          if (ps == 0) load_cb(rb_next);
+          if (ps == 2) park_cb();
         }
-        const half8 h0 = __builtin_bit_cast(half8, F[xs][2 * s]);
-        const half8 l0 = __builtin_bit_cast(half8, F[xs][2 * s + 1]);
 #pragma unroll
-        for (int bp = 0; bp < 4; ++bp) {
-          if (bp < 3) {
+        for (int s = 0; s < 2; ++s) {
+          half8 nx[2][2];
+          const half8 h0 = __builtin_bit_cast(half8, F[xs][2 * s]);
+          const half8 l0 = __builtin_bit_cast(half8, F[xs][2 * s + 1]);
 #pragma unroll
-            for (int o = 0; o < 2; ++o) {
-              nx[o][0] = w[(s * 16 + 4 * bp + 4 + 2 * o) * 64];
-              nx[o][1] = w[(s * 16 + 4 * bp + 5 + 2 * o) * 64];
+          for (int bp = 0; bp < 4; ++bp) {
+            if (bp < 3) {
+#pragma unroll
+              for (int o = 0; o < 2; ++o) {
+                nx[o][0] = w[(s * 16 + 4 * bp + 4 + 2 * o) * 64];
+                nx[o][1] = w[(s * 16 + 4 * bp + 5 + 2 * o) * 64];
+              }
+            } else if (s == 0) {
+#pragma unroll
+              for (int o = 0; o < 2; ++o) {
+                nx[o][0] = w[(16 + 2 * o) * 64];
+                nx[o][1] = w[(16 + 2 * o + 1) * 64];
+              }
+            } else {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int o = 0; o < 2; ++o) {
+                nx[o][0] = wn[(2 * o) * 64];
+                nx[o][1] = wn[(2 * o + 1) * 64];
+              }
             }
-          }
-          const int b0 = 2 * bp, b1 = 2 * bp + 1;
-          acc[b0] = mfma(c[0][0], h0, acc[b0]);
-          acc[b1] = mfma(c[1][0], h0, acc[b1]);
-          acc[b0] = mfma(c[0][0], l0, acc[b0]);
-          acc[b1] = mfma(c[1][0], l0, acc[b1]);
-          acc[b0] = mfma(c[0][1], h0, acc[b0]);
-          acc[b1] = mfma(c[1][1], h0, acc[b1]);
-          if (!(bp & 1)) dma(doff, (ps + 3) & 3, 2 * s + (bp >> 1));
+            const int b0 = 2 * bp, b1 = 2 * bp + 1;
+            acc[b0] = mfma(c[0][0], h0, acc[b0]);
+            acc[b1] = mfma(c[1][0], h0, acc[b1]);
+            acc[b0] = mfma(c[0][0], l0, acc[b0]);
+            acc[b1] = mfma(c[1][0], l0, acc[b1]);
+            acc[b0] = mfma(c[0][1], h0, acc[b0]);
+            acc[b1] = mfma(c[1][1], h0, acc[b1]);
+            if (!(bp & 1)) dma(doff, (ps + 3) & 3, 2 * s + (bp >> 1));
 #pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (q < 4 && bp < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (q == 3 && !(bp & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (bp < 3) {
+            for (int q = 0; q < 6; ++q) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if (q == 3 && !(bp & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
               c[o][0] = nx[o][0];
               c[o][1] = nx[o][1];
             }
           }
-        }
-        // this k step's fragments are consumed (the matrix instructions above have read them): reload the
-        // registers with the same k step of piece p + 2
-        if (load_next) {
+          // this k step's fragments are consumed (the matrix instructions above have read them): reload the
+          // registers with the same k step of piece p + 2 (of the next tile's first pieces near the end)
           if (s == 0) load_k0(xs);
           else load_k1(xs);
+          wait_vm<12>();
         }
-        wait_vm<12>();
+        // piece p + 3 is what the loads issued during piece p + 1 fetch: past this tile's end, the next tile's piece 0
+        xp = (ps == 1 && p4 + 4 == np) ? next_base : xp + FRAG_BLOCK_BYTES;
+        doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
       }
-      if (load_next) xp += FRAG_BLOCK_BYTES;
-      doff = doff + R_PIECE_BYTES < wbytes ? doff + R_PIECE_BYTES : 0;
-      __builtin_amdgcn_s_barrier();
     }
+    // ---- tile boundary: the operand streams of the next tile are already in flight; only the accumulators turn over
+    if (STORE) frag_epilogue(g, acc, rb, lane, n0);
+    if (g.pool) {
+      Args gz = g;                    // bias + group bias are already in the accumulators
+      gz.bias = g.zeros;
+      gz.gbias = g.zeros;
+      gz.gbias_stride = 0;
+      pool_epilogue(gz, reinterpret_cast<unsigned char *>(red), acc, wave, lane, m0, n0);
+    }
+    start_acc();
+    rb = rb_next;
   }
-  wait_vm<0>();
-  __builtin_amdgcn_s_barrier();    // every wave's W transfers have landed: the ring is free
-  if (STORE) frag_epilogue(g, acc, rb, lane, m0, n0);
-  if (g.pool) pool_epilogue(g, smem, acc, wave, lane, m0, n0);
+  wait_vm<0>();                       // the last tile's look-ahead transfers: nothing may be in flight at s_endpgm
 }
 
 }  // namespace
@@ -1023,7 +1117,20 @@ RFD_API int rfd_gemm_f16x3_frag(int M, int N, int K, const void *A_frag, long a_
   g.status = rfd_status_word(ws, (hipStream_t)stream);
   g.Af = (const unsigned char *)A_frag; g.af_stride = a_rb_stride;
   g.Cf = (unsigned char *)C_frag; g.cf_stride = c_rb_stride;
-  const dim3 grid((M / RM) * (N / RN));
+  g.zeros = ws->zeros;
+  g.cb1 = gbias; g.cb1_stride = gbias ? N : 0;
+  g.cb2 = bias; g.cb2_stride = 0;
+  // persistent: one workgroup per CU (144 KiB of LDS each), a multiple of the n tiles so that a workgroup keeps ONE W
+  // stream, and of 8 x n tiles when possible (XCD-aware tile lists, see the kernel)
+  const int ntiles = N / RN, tiles = (M / RM) * ntiles;
+  int nwg = ws->num_cu / (8 * ntiles) * (8 * ntiles);
+  if (nwg == 0) nwg = ws->num_cu / ntiles * ntiles;
+  if (nwg == 0) nwg = ntiles;
+  if (nwg > tiles) nwg = tiles;
+  // cb2 is always dereferenced (one code path): zeros when absent
+  if (!g.cb1) { g.cb1 = ws->zeros; g.cb1_stride = 0; }
+  if (!g.cb2) { g.cb2 = ws->zeros; g.cb2_stride = 0; }
+  const dim3 grid(nwg);
   if (C_frag) hipLaunchKernelGGL((gemm_rowsf_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, g);
   else hipLaunchKernelGGL((gemm_rowsf_kernel<false>), grid, dim3(512), 0, (hipStream_t)stream, g);
   RFD_CHECK_LAUNCH();
