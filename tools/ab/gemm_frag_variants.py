@@ -13,7 +13,8 @@ from rfdnet_amd import build as B  # noqa: E402
 
 VARIANTS = {"gf_base": [], "gf_noxload": ["-DAB_NOXLOAD"], "gf_nodma": ["-DAB_NODMA"], "gf_nolds": ["-DAB_NOLDS"],
             "gf_nobar": ["-DAB_NOBARRIER"], "gf_noepi": ["-DAB_NOEPI"], "gf_nomem": ["-DAB_NOXLOAD", "-DAB_NODMA"],
-            "gf_nostore": ["-DAB_NOSTORE"], "gf_nopool": ["-DAB_NOPOOL"],
+            "gf_nostore": ["-DAB_NOSTORE"], "gf_nopool": ["-DAB_NOPOOL"], "gf_noxwait": ["-DAB_NOXWAIT"], "gf_xsame": ["-DAB_XSAME"],
+            "gf_xsame_nostore": ["-DAB_XSAME", "-DAB_NOSTORE"],
             "gf_mfmaonly": ["-DAB_NOXLOAD", "-DAB_NODMA", "-DAB_NOLDS", "-DAB_NOBARRIER", "-DAB_NOEPI"]}
 
 
