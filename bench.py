@@ -780,8 +780,10 @@ def run_job(args, be, rank, world, dist):
         mine = [first + j for j in sharding.scene_ids_for_rank(args.scenes, rank, world)]
         plan = [sharding.scene_ids_for_worker(mine, w, S, NB) for w in range(S)]
     t0 = time.perf_counter()
+    cpu0 = time.process_time()                               # CPU seconds of every thread of this rank
     res = list(pool.map(lambda w: worker(w, plan[w]), range(S)))
     be.sync()
+    be.host_cpu_s = time.process_time() - cpu0               # (before the barrier: a waiting rank may spin in it)
     if dist is not None:
         dist.barrier()
     be.sync()
@@ -1044,6 +1046,9 @@ def main(argv=None):
                        "vertices_per_scene": int(gathered[:, F("n_vertices")].sum() / per),
                        "hbm_peak_gib": round(be.torch.cuda.max_memory_reserved() / 2.0 ** 30, 2)
                        if be.name != "stub" else None,
+                       # host CPU seconds rank 0 spent per scene inside the timed region (all its threads): what
+                       # 8 ranks x `scenes_in_flight` threads ask of the node's cores
+                       "host_cpu_s_per_scene_rank0": round(getattr(be, "host_cpu_s", 0.0) / max(float(gathered[0, F("steps")]), 1.0), 5),
                        "scenes_in_flight_per_gpu": be.S * be.NB, "scenes_per_forward": be.NB,
                        "scenes_per_step": be.S * be.NB * world, "scenes_done": int(scenes_total),
                        "scenes_failed": failed, "scenes_retried_after_fps_abort": int(getattr(be, "retried", 0)),

@@ -13,8 +13,9 @@ from rfdnet_amd import build as B  # noqa: E402
 
 VARIANTS = {"gf_base": [], "gf_noxload": ["-DAB_NOXLOAD"], "gf_nodma": ["-DAB_NODMA"], "gf_nolds": ["-DAB_NOLDS"],
             "gf_nobar": ["-DAB_NOBARRIER"], "gf_noepi": ["-DAB_NOEPI"], "gf_nomem": ["-DAB_NOXLOAD", "-DAB_NODMA"],
-            "gf_nostore": ["-DAB_NOSTORE"], "gf_nopool": ["-DAB_NOPOOL"], "gf_noxwait": ["-DAB_NOXWAIT"], "gf_xsame": ["-DAB_XSAME"],
-            "gf_xsame_nostore": ["-DAB_XSAME", "-DAB_NOSTORE"],
+            "gf_nostore": ["-DAB_NOSTORE"], "gf_nopool": ["-DAB_NOPOOL"], "gf_noxwait": ["-DAB_NOXWAIT"], "gf_xsame": ["-DAB_XSAME=8"],
+            "gf_xsame_nostore": ["-DAB_XSAME=8", "-DAB_NOSTORE"], "gf_xmall512": ["-DAB_XSAME=512"],
+            "gf_xmall1024": ["-DAB_XSAME=1024"], "gf_xmall2048": ["-DAB_XSAME=2048"],
             "gf_mfmaonly": ["-DAB_NOXLOAD", "-DAB_NODMA", "-DAB_NOLDS", "-DAB_NOBARRIER", "-DAB_NOEPI"]}
 
 
