@@ -962,6 +962,13 @@ __global__ __launch_bounds__(512) void gemm_rowsf_kernel(Args g) {
           if (s == 0) load_k0(xs);
           else load_k1(xs);
           wait_vm<12>();
+          // The loads are opaque to the compiler: it believes F was written when the asm was issued and will move
+          // the next k step's first matrix instruction ABOVE the wait (tools/audit_vmcnt.py caught exactly that in
+          // the first build).  Volatile asm statements keep their order, so these empty ones stay behind the wait,
+          // and the fragments the next k step reads now depend on them.
+          if (s == 0) asm volatile("" : "+v"(F[xs][2]), "+v"(F[xs][3]));
+          else asm volatile("" : "+v"(F[xs ^ 1][0]), "+v"(F[xs ^ 1][1]));
+          __builtin_amdgcn_sched_barrier(0);
         }
         // piece p + 3 is what the loads issued during piece p + 1 fetch: past this tile's end, the next tile's piece 0
         xp = (ps == 1 && p4 + 4 == np) ? next_base : xp + FRAG_BLOCK_BYTES;

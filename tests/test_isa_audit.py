@@ -32,6 +32,14 @@ def test_row_owner_gemm_has_no_use_before_landed(tmp_path):
         seen, problems = audit_vmcnt.audit(asm, "gemm_rows8_kernel" + variant)
         assert seen['loads'] >= 40 and seen['waits'] >= 8, seen      # the audit saw the hand-issued loads
         assert problems == [], problems[:5]
+    # round 6: the persistent frag-rows kernel issues its B fragments AND its accumulator start values with opaque
+    # loads; its first build let the compiler lift a matrix instruction above the `s_waitcnt vmcnt(12)` that covers its
+    # operand (two sites, found by this audit, never seen to fail on hardware) -- fixed by tying the fragments to an
+    # empty volatile asm behind the wait
+    for variant in ("ILb1E", "ILb0E"):
+        seen, problems = audit_vmcnt.audit(asm, "gemm_rowsf_kernel" + variant)
+        assert seen['loads'] >= 40 and seen['waits'] >= 16, seen
+        assert problems == [], problems[:5]
 
 
 def _asm(tmp_path, src, name, extra=()):
@@ -80,8 +88,13 @@ def test_shipped_kernels_carry_no_wrong_result_switch_and_the_ablation_patch_reb
     shipped = _asm(tmp_path, "occ_decoder8.hip", "dec8_shipped.s")
     patched = _asm(tmp_path, _ablation_source(tmp_path), "dec8_patched.s")
     assert _code_lines(shipped) == _code_lines(patched)
-    # the two phase-stamp patches (tools/fps_trace.py, tools/dec_trace.py) still apply and compile with their switch
+    # round 6: the same rule for the frag-rows GEMM's timing-only switches (AB_NOXLOAD, AB_NODMA, ...:
+    # tools/ab/gemm_frag_ablation.patch, built by tools/ab/gemm_frag_variants.py)
+    assert not re.search(r"\bAB_[A-Z]", open(os.path.join(csrc, "gemm_f16x3.hip")).read())
     import build_variants
+    gsrc = build_variants.patched_source("gemm_f16x3.hip", "gemm_frag_ablation.patch", str(tmp_path / "gemm_ab_src"))
+    assert _code_lines(_asm(tmp_path, "gemm_f16x3.hip", "gemm_shipped.s")) == _code_lines(_asm(tmp_path, gsrc, "gemm_patched.s"))
+    # the two phase-stamp patches (tools/fps_trace.py, tools/dec_trace.py) still apply and compile with their switch
     for src, patch, flag in (("sampling.hip", "fps_trace.patch", "-DRFD_FPS_TRACE"),
                              ("occ_decoder.hip", "dec4_trace.patch", "-DRFD_DECODE_TRACE")):
         traced = build_variants.patched_source(src, patch, str(tmp_path / "trace_src"))
