@@ -288,6 +288,15 @@ int rfd_chain_pack(int mode, const float *W1, const float *W2, const float *W3, 
 int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int ldx, const void *packed,
                    const float *W1raw, const float *b1, const float *b2, const float *b3, int relu3, int sa,
                    int sw1, int sw2, int sw3, float *out, void *stream);
+/* the same chain with a last layer of c3 channels, a multiple of 64 up to 1024 (W3 [c3][128], b3 [c3], out [M / P][c3]):
+ * 256 = the STN3d of STN_Group (pointnet2_modules.py:420-466: conv 3 -> 64 -> 128 -> 256 + BatchNorms + ReLU + max over
+ * the group's points); rfd_chain_pack / rfd_chain_pool are the c3 = 1024 case */
+size_t rfd_chain_packed_bytes_n(int c3);
+int rfd_chain_pack_n(int mode, int c3, const float *W1, const float *W2, const float *W3, int sw1, int sw2, int sw3,
+                     void *packed, void *stream);
+int rfd_chain_pool_n(int mode, int c3, int M, int P, int d_in, const float *x, int ldx, const void *packed,
+                     const float *W1raw, const float *b1, const float *b2, const float *b3, int relu3, int sa,
+                     int sw1, int sw2, int sw3, float *out, void *stream);
 
 /* PointSeg's per-point head fused (csrc/pointseg_chain.hip; pointseg.py:131-154 with the BatchNorms folded):
  *   x [M][ldx] (64-wide point feature) -> 64 -> 512 (+ gbias[row / P], ReLU) -> 256 (ReLU) -> 128 (ReLU) -> n_cls scores

@@ -60,6 +60,8 @@ SIGNATURES = {
     "rfd_mc_blocks": [_i],
     "rfd_chain_pack": [_i, _f, _f, _f, _i, _i, _i, _f, _f],
     "rfd_chain_pool": [_i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f],
+    "rfd_chain_pack_n": [_i, _i, _f, _f, _f, _i, _i, _i, _f, _f],
+    "rfd_chain_pool_n": [_i, _i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f],
     "rfd_head_pack": [_f, _f, _f, _i, _i, _i, _f, _f],
     "rfd_head_scores": [_i, _i, _f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f],
     "rfd_pos_embed": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _f],
@@ -75,7 +77,7 @@ _RESTYPES = {
     "rfd_occ_packed_bytes": C.c_size_t,
 }
 _INT_FNS = {"rfd_stream_status": [_f], "rfd_release_stream": [_f], "rfd_stream_status_snapshot": [_f, _f]}
-_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_frag_bytes": [_i, _i], "rfd_chain_packed_bytes": [], "rfd_head_packed_bytes": []}
+_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_frag_bytes": [_i, _i], "rfd_chain_packed_bytes": [], "rfd_chain_packed_bytes_n": [_i], "rfd_head_packed_bytes": []}
 
 _lib = None
 

@@ -1,5 +1,6 @@
 """The PointNet feature chains of the skip-propagation nets as one kernel each (csrc/pointseg_chain.hip):
-[d -> 64, ReLU] -> 64 -> 128, ReLU -> 128 -> 1024 [, ReLU] -> max over the P points of a proposal, on the split-f16
+[d -> 64, ReLU] -> 64 -> 128, ReLU -> 128 -> C3 [, ReLU] -> max over the P points of a proposal (C3 = 1024 for
+PointSeg's encoders, 256 for STN_Group's STN3d; any multiple of 64 up to 1024), on the split-f16
 matrix-core arithmetic of gemm.py (fp32-class).  Weights are (W (N,K), b (N)) with BatchNorm already folded in
 (fold_bn.folded); they are split / re-laid once and cached per parameter version."""
 import os
@@ -43,15 +44,17 @@ def _packed(mode, layers):
     key = tuple((None if w is None else (w.data_ptr(), w._version, tuple(w.shape))) for w in (W1, W2, W3)) + (mode,)
 
     def build():
-        assert tuple(W2.shape) == (128, 64) and tuple(W3.shape) == (1024, 128), (W2.shape, W3.shape)
+        c3 = W3.shape[0]
+        assert tuple(W2.shape) == (128, 64) and W3.shape[1] == 128 and c3 % 64 == 0 and 64 <= c3 <= 1024, \
+            (W2.shape, W3.shape)
         sw1 = occ_fold.choose_kw([W1]) if mode == 2 else 0
         sw2, sw3 = occ_fold.choose_kw([W2]), occ_fold.choose_kw([W3])
-        buf = torch.empty(_lib.lib().rfd_chain_packed_bytes(), dtype=torch.uint8, device=W2.device)
+        buf = torch.empty(_lib.lib().rfd_chain_packed_bytes_n(c3), dtype=torch.uint8, device=W2.device)
         w1c = W1.contiguous() if mode == 2 else None
         w2c, w3c = W2.contiguous(), W3.contiguous()
         with torch.cuda.device(W2.device):
-            rc = _lib.lib().rfd_chain_pack(mode, w1c.data_ptr() if w1c is not None else None, w2c.data_ptr(),
-                                           w3c.data_ptr(), sw1, sw2, sw3, buf.data_ptr(), _lib.current_stream())
+            rc = _lib.lib().rfd_chain_pack_n(mode, c3, w1c.data_ptr() if w1c is not None else None, w2c.data_ptr(),
+                                             w3c.data_ptr(), sw1, sw2, sw3, buf.data_ptr(), _lib.current_stream())
         _lib.check(rc, "rfd_chain_pack")
         torch.cuda.current_stream(W2.device).synchronize()          # w?c may be temporaries
         return (buf, sw1, sw2, sw3, (W1, W2, W3))                    # keep the keyed tensors alive
@@ -60,7 +63,8 @@ def _packed(mode, layers):
 
 def chain_pool(x, layer1, layer2, layer3, P, relu3):
     """x (M, d); layer1 = (W1 (64,d), b1) or None (x is already the 64-wide feature); layer2 = (W2 (128,64), b2);
-    layer3 = (W3 (1024,128), b3) -> (M / P, 1024) = max over each proposal's points of the chain's output."""
+    layer3 = (W3 (C3,128), b3), C3 a multiple of 64 up to 1024 -> (M / P, C3) = max over each proposal's points of the
+    chain's output."""
     M, d = x.shape
     if layer1 is None:
         mode, layer1 = 0, (None, None)
@@ -69,12 +73,13 @@ def chain_pool(x, layer1, layer2, layer3, P, relu3):
         assert tuple(layer1[0].shape) == (64, d), layer1[0].shape
     assert usable(x, P, d)
     buf, sw1, sw2, sw3, _ = _packed(mode, (layer1, layer2, layer3))
-    out = torch.empty(M // P, 1024, dtype=torch.float32, device=x.device)
+    c3 = layer3[0].shape[0]
+    out = torch.empty(M // P, c3, dtype=torch.float32, device=x.device)
     w1raw = layer1[0].contiguous() if mode == 1 else None
     b1 = layer1[1].contiguous() if mode else None
     b2, b3 = layer2[1].contiguous(), layer3[1].contiguous()
     with torch.cuda.device(x.device):
-        rc = _lib.lib().rfd_chain_pool(mode, M, P, d, x.data_ptr(), x.stride(0), buf.data_ptr(),
+        rc = _lib.lib().rfd_chain_pool_n(mode, c3, M, P, d, x.data_ptr(), x.stride(0), buf.data_ptr(),
                                        w1raw.data_ptr() if w1raw is not None else None,
                                        b1.data_ptr() if b1 is not None else None, b2.data_ptr(), b3.data_ptr(),
                                        int(bool(relu3)), gemm.SA, sw1, sw2, sw3, out.data_ptr(), _lib.current_stream())

@@ -25,10 +25,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-constexpr int C1 = 64, C2 = 128, C3 = 1024;
+constexpr int C1 = 64, C2 = 128, C3 = 1024;           // C3: the LARGEST last-layer width (LDS is sized for it)
 constexpr int PIECE = 32 * 1024;                       // 4 output tiles of the last layer x (4 k-steps x hi, lo) x 1 KiB
-constexpr int N_PIECES = C3 / 16 / 4;                  // 16
-constexpr int W3_BYTES = N_PIECES * PIECE;             // 512 KiB
+constexpr int N_PIECES = C3 / 16 / 4;                  // 16 at the largest width
+constexpr int W3_BYTES = N_PIECES * PIECE;             // 512 KiB at the largest width
+// the last layer's width c3 is a run-time multiple of 64 (one 32-KiB piece per 64 channels): 1024 for the PointNet
+// encoders of pointseg.py, 256 for STN_Group's STN3d (pointnet2_modules.py:420-466)
+__host__ __device__ inline int chain_pieces(int c3) { return c3 / 64; }
 constexpr int W2_BYTES = (C2 / 16) * 2 * 2 * 1024;     // 8 tiles x 2 k-steps x (hi, lo): 32 KiB
 constexpr int W1_BYTES = (C1 / 16) * 2 * 2 * 1024;     // 4 tiles x 2 k-steps x (hi, lo): 16 KiB
 constexpr int OFF_W2 = 3 * PIECE, OFF_W1 = OFF_W2 + W2_BYTES, OFF_B = OFF_W1 + W1_BYTES;
@@ -42,10 +45,11 @@ __device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
 // k order of a 32-wide k-step whose operand is a previous layer's accumulators: lane group kg, slot j
 __host__ __device__ inline int chain_k(int ks, int kg, int j) { return 32 * ks + 16 * (j >> 2) + 4 * kg + (j & 3); }
 
-// packed = [W3 stream 512 KiB][W2 32 KiB][W1 16 KiB]; every fragment = 64 lanes x 8 halves
-__global__ void chain_pack_kernel(int mode, const float *__restrict__ W1, const float *__restrict__ W2,
+// packed = [W3 stream c3 / 64 x 32 KiB][W2 32 KiB][W1 16 KiB]; every fragment = 64 lanes x 8 halves
+__global__ void chain_pack_kernel(int mode, int c3, const float *__restrict__ W1, const float *__restrict__ W2,
                                   const float *__restrict__ W3, int sw1, int sw2, int sw3, _Float16 *__restrict__ packed) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t W3_BYTES = (size_t)chain_pieces(c3) * PIECE;          // (shadows the largest-width constant)
   const size_t total = (size_t)(W3_BYTES + W2_BYTES + W1_BYTES) / 2;
   if (e >= total) return;
   const int j = e & 7, lane = (e >> 3) & 63, idx = lane & 15, kg = lane >> 4;
@@ -107,7 +111,7 @@ __device__ __forceinline__ void act_pair(const f32x4 &x0, const f32x4 &x1, const
 }
 
 struct ChainArgs {
-  int M, P, d_in, ldx, relu3;
+  int M, P, d_in, ldx, relu3, c3;
   const float *x;
   const half8 *packed;
   const float *W1raw, *b1, *b2, *b3;
@@ -132,24 +136,25 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a) {
   const int prop = blockIdx.x;
   const char *gp = reinterpret_cast<const char *>(a.packed);
   unsigned amax16 = 0u;
+  const int c3 = a.c3, n_pieces = chain_pieces(c3);     // run-time last-layer width
 
   // ---- per-workgroup constants: the two small layers' fragments, biases, pooled maxima
   {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(gp + W3_BYTES);
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(gp + (size_t)n_pieces * PIECE);
     u32x4 *dst = reinterpret_cast<u32x4 *>(smem + OFF_W2);
     for (int i = t; i < (W2_BYTES + (MODE == 2 ? W1_BYTES : 0)) / 16; i += 512) dst[i] = src[i];
     for (int i = t; i < C1; i += 512) s_b1[i] = MODE ? a.b1[i] : 0.f;
     for (int i = t; i < C2; i += 512) s_b2[i] = a.b2[i];
-    for (int i = t; i < C3; i += 512) {
+    for (int i = t; i < c3; i += 512) {
       s_b3[i] = a.b3[i];
       s_red[i] = -__builtin_inff();
     }
     if (MODE == 1)
       for (int i = t; i < C1 * 8; i += 512) s_w1[i] = (i & 7) < a.d_in ? a.W1raw[(i >> 3) * a.d_in + (i & 7)] : 0.f;
   }
-  const int pts_per_wave = a.P / 8, passes = pts_per_wave / 64, total_pieces = passes * N_PIECES;
+  const int pts_per_wave = a.P / 8, passes = pts_per_wave / 64, total_pieces = passes * n_pieces;
   auto dma_piece = [&](int p) {          // wave w moves fragments 4w .. 4w+3 of piece p (32 fragments)
-    const char *src = gp + (size_t)(p % N_PIECES) * PIECE + (wave * 4) * 1024 + lane * 16;
+    const char *src = gp + (size_t)(p % n_pieces) * PIECE + (wave * 4) * 1024 + lane * 16;
     unsigned char *dst = smem + (p % 3) * PIECE + (wave * 4) * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a) {
     }
 
     // ---- 128 -> 1024 with the operands swapped (A = activations, B = weights) + max over the wave's 64 points
-    for (int i = 0; i < N_PIECES; ++i) {
-      const int p = pass * N_PIECES + i;
+    for (int i = 0; i < n_pieces; ++i) {
+      const int p = pass * n_pieces + i;
       if (p + 2 < total_pieces) dma_piece(p + 2);
       const half8 *w3 = reinterpret_cast<const half8 *>(smem + (p % 3) * PIECE) + lane;
       // fragments of a tile: 4 k-steps x (hi, lo); the next tile's are fetched under this tile's 48 MFMAs into the OTHER
@@ -310,10 +315,10 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a) {
     }
   }
   // ---- out[prop][c] = relu?(max * 2^-(sa+sw3) + b3[c])   (max commutes with the positive scale, the bias and the ReLU)
-  for (int c = t; c < C3; c += 512) {
+  for (int c = t; c < c3; c += 512) {
     float o = __builtin_fmaf(s_red[c], a.os3, s_b3[c]);
     if (a.relu3) o = o > 0.f ? o : 0.f;
-    a.out[(size_t)prop * C3 + c] = o;
+    a.out[(size_t)prop * c3 + c] = o;
     // the pooled feature is the next split-precision layer's INPUT (STN fc1, PointSeg's conv1 share): watch what is
     // stored, like the row-owner GEMM's pool path does -- |o| 2^sa beyond f16 would saturate there silently
     if (fabsf(o) * a.ascale >= 65504.f) atomicOr(a.status, 4u);
@@ -544,32 +549,43 @@ __global__ __launch_bounds__(512) void head_kernel(HeadArgs a) {
 
 }  // namespace
 
-RFD_API size_t rfd_chain_packed_bytes(void) { return (size_t)W3_BYTES + W2_BYTES + W1_BYTES; }
+static bool chain_width_ok(int c3) { return c3 >= 64 && c3 <= C3 && c3 % 64 == 0; }
 
-// W1 [64][64] (mode 2) or NULL, W2 [128][64], W3 [1024][128]: fp32, BatchNorm already folded in by the caller.
-RFD_API int rfd_chain_pack(int mode, const float *W1, const float *W2, const float *W3, int sw1, int sw2, int sw3,
-                           void *packed, void *stream) {
-  if (mode < 0 || mode > 2 || !W2 || !W3 || (mode == 2 && !W1)) {
-    rfd_set_error("rfd_chain_pack: mode / weights", hipErrorInvalidValue);
+RFD_API size_t rfd_chain_packed_bytes_n(int c3) {
+  return chain_width_ok(c3) ? (size_t)chain_pieces(c3) * PIECE + W2_BYTES + W1_BYTES : 0;
+}
+RFD_API size_t rfd_chain_packed_bytes(void) { return rfd_chain_packed_bytes_n(C3); }
+
+// W1 [64][64] (mode 2) or NULL, W2 [128][64], W3 [c3][128]: fp32, BatchNorm already folded in by the caller.
+// c3: the last layer's width, a multiple of 64 up to 1024.
+RFD_API int rfd_chain_pack_n(int mode, int c3, const float *W1, const float *W2, const float *W3, int sw1, int sw2,
+                             int sw3, void *packed, void *stream) {
+  if (mode < 0 || mode > 2 || !W2 || !W3 || (mode == 2 && !W1) || !chain_width_ok(c3)) {
+    rfd_set_error("rfd_chain_pack: mode / weights / width (64 .. 1024, multiple of 64)", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
-  const size_t total = rfd_chain_packed_bytes() / 2;
+  const size_t total = rfd_chain_packed_bytes_n(c3) / 2;
   hipLaunchKernelGGL(chain_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mode,
-                     W1, W2, W3, sw1, sw2, sw3, (_Float16 *)packed);
+                     c3, W1, W2, W3, sw1, sw2, sw3, (_Float16 *)packed);
   RFD_CHECK_LAUNCH();
   return 0;
 }
+RFD_API int rfd_chain_pack(int mode, const float *W1, const float *W2, const float *W3, int sw1, int sw2, int sw3,
+                           void *packed, void *stream) {
+  return rfd_chain_pack_n(mode, C3, W1, W2, W3, sw1, sw2, sw3, packed, stream);
+}
 
 // x [M][ldx] fp32 rows (d_in <= 8 columns used in mode 1, 64 otherwise; 16-byte aligned rows for modes 0 / 2),
-// P points per proposal (P % 512 == 0: 8 waves x 64 points), out [M / P][1024].
-RFD_API int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int ldx, const void *packed,
-                           const float *W1raw, const float *b1, const float *b2, const float *b3, int relu3, int sa,
-                           int sw1, int sw2, int sw3, float *out, void *stream) {
+// P points per proposal (P % 512 == 0: 8 waves x 64 points), out [M / P][c3].
+RFD_API int rfd_chain_pool_n(int mode, int c3, int M, int P, int d_in, const float *x, int ldx, const void *packed,
+                             const float *W1raw, const float *b1, const float *b2, const float *b3, int relu3, int sa,
+                             int sw1, int sw2, int sw3, float *out, void *stream) {
   if (M <= 0) return 0;
   if (mode < 0 || mode > 2 || P <= 0 || P % 512 || M % P || (mode == 1 && (d_in < 1 || d_in > 8 || !W1raw)) ||
-      (mode != 1 && (d_in != 64 || (ldx & 3) || ((uintptr_t)x & 15))) || (mode && !b1) || !b2 || !b3 || !out) {
-    rfd_set_error("rfd_chain_pool: need P % 512 == 0, M % P == 0, d_in <= 8 (mode 1) or 64 with 16-byte rows",
-                  hipErrorInvalidValue);
+      (mode != 1 && (d_in != 64 || (ldx & 3) || ((uintptr_t)x & 15))) || (mode && !b1) || !b2 || !b3 || !out ||
+      !chain_width_ok(c3)) {
+    rfd_set_error("rfd_chain_pool: need P % 512 == 0, M % P == 0, d_in <= 8 (mode 1) or 64 with 16-byte rows, "
+                  "last width 64 .. 1024 in steps of 64", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
   RfdWorkspace *ws;
@@ -578,7 +594,7 @@ RFD_API int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int
     if (rc) return rc;
   }
   ChainArgs a;
-  a.M = M; a.P = P; a.d_in = d_in; a.ldx = ldx; a.relu3 = relu3; a.x = x; a.packed = (const half8 *)packed;
+  a.M = M; a.P = P; a.d_in = d_in; a.ldx = ldx; a.relu3 = relu3; a.c3 = c3; a.x = x; a.packed = (const half8 *)packed;
   a.W1raw = W1raw; a.b1 = b1; a.b2 = b2; a.b3 = b3;
   a.ascale = ldexpf(1.f, sa); a.os1 = ldexpf(1.f, -(sa + sw1)); a.os2 = ldexpf(1.f, -(sa + sw2));
   a.os3 = ldexpf(1.f, -(sa + sw3));
@@ -591,6 +607,11 @@ RFD_API int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int
   else hipLaunchKernelGGL(chain_kernel<2>, grid, block, 0, s, a);
   RFD_CHECK_LAUNCH();
   return 0;
+}
+RFD_API int rfd_chain_pool(int mode, int M, int P, int d_in, const float *x, int ldx, const void *packed,
+                           const float *W1raw, const float *b1, const float *b2, const float *b3, int relu3, int sa,
+                           int sw1, int sw2, int sw3, float *out, void *stream) {
+  return rfd_chain_pool_n(mode, C3, M, P, d_in, x, ldx, packed, W1raw, b1, b2, b3, relu3, sa, sw1, sw2, sw3, out, stream);
 }
 
 RFD_API size_t rfd_head_packed_bytes(void) { return (size_t)H_PIECES * HPIECE; }

@@ -163,11 +163,19 @@ def _stn3d_affine_rows(stn, rows):
     """STN3d's regressor on row-major points: rows (B', P, 3) -> (B', 3, 4).  Eval-mode
     BatchNorms folded into the layers; wide layers on the split-precision GEMM."""
     from ..fold_bn import folded, linear_rows
+    from .. import chain
     Bp, P, _ = rows.shape
-    h = linear_rows(rows.reshape(Bp * P, 3), *folded(stn.conv1, stn.bn1), relu=True)
-    h = linear_rows(h, *folded(stn.conv2, stn.bn2), relu=True)
-    h = linear_rows(h, *folded(stn.conv3, stn.bn3), relu=True)
-    g = h.view(Bp, P, -1).max(dim=1)[0]
+    x2 = rows.reshape(Bp * P, 3)
+    if chain.usable(x2, P, 3):
+        # conv1..3 + BatchNorms + ReLU + the max over the group's points as ONE kernel (csrc/pointseg_chain.hip with a
+        # 256-wide last layer): the 64- / 128- / 256-wide intermediates of 262 144 points (470 MB) never reach HBM
+        g = chain.chain_pool(x2, folded(stn.conv1, stn.bn1), folded(stn.conv2, stn.bn2), folded(stn.conv3, stn.bn3),
+                             P, True)
+    else:
+        h = linear_rows(x2, *folded(stn.conv1, stn.bn1), relu=True)
+        h = linear_rows(h, *folded(stn.conv2, stn.bn2), relu=True)
+        h = linear_rows(h, *folded(stn.conv3, stn.bn3), relu=True)
+        g = h.view(Bp, P, -1).max(dim=1)[0]
     g = linear_rows(g, *folded(stn.fc1, stn.bn4), relu=True)
     g = linear_rows(g, *folded(stn.fc2, stn.bn5), relu=True)
     g = F.linear(g, stn.fc3.weight, stn.fc3.bias)

@@ -17,14 +17,14 @@ def reference(x, l1, l2, l3, P, relu3):
     h = h @ l3[0].double().t() + l3[1].double()
     if relu3:
         h = torch.relu(h)
-    return h.view(-1, P, 1024).max(dim=1)[0]
+    return h.view(-1, P, l3[0].shape[0]).max(dim=1)[0]
 
 
-def layers(g, d):
+def layers(g, d, c3=1024):
     def lin(n, k, scale):
         return ((torch.rand(n, k, device="cuda", generator=g) * 2 - 1) * scale / np.sqrt(k),
                 torch.randn(n, device="cuda", generator=g) * 0.3)
-    return (lin(64, d, 2.0) if d else None), lin(128, 64, 2.0), lin(1024, 128, 2.0)
+    return (lin(64, d, 2.0) if d else None), lin(128, 64, 2.0), lin(c3, 128, 2.0)
 
 
 @pytest.mark.parametrize("mode,d,relu3,B,P", [(1, 4, True, 3, 1024), (1, 3, True, 2, 512), (1, 7, True, 1, 1024),
@@ -52,6 +52,51 @@ def test_chain_matches_fp64_composition(hip, mode, d, relu3, B, P):
     if not relu3:
         assert (ref < 0).any()
     assert err < 2e-5
+
+
+@pytest.mark.parametrize("c3,mode,d,relu3,B,P", [(256, 1, 3, True, 5, 1024), (64, 1, 3, True, 2, 512),
+                                                  (320, 0, 0, False, 3, 1024), (960, 2, 64, True, 2, 1024)])
+def test_chain_with_a_narrower_last_layer(hip, c3, mode, d, relu3, B, P):
+    """round 6: the last layer's width is a run-time multiple of 64 (256 = STN_Group's STN3d,
+    pointnet2_modules.py:420-466); widths whose piece count does not divide the ring's three slots included"""
+    from rfdnet_amd import chain
+    g = torch.Generator(device="cuda").manual_seed(c3 + d)
+    l1, l2, l3 = layers(g, d, c3)
+    if not relu3:
+        l3 = (l3[0], l3[1] - 3.0)
+    din = d if mode else 64
+    x = torch.randn(B * P, din, device="cuda", generator=g) * 1.5
+    out = chain.chain_pool(x, l1, l2, l3, P, relu3)
+    hip.device_status()
+    ref = reference(x, l1, l2, l3, P, relu3)
+    assert out.shape == (B, c3)
+    assert (out.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()) < 2e-5
+    with pytest.raises(AssertionError):
+        chain.chain_pool(x, l1, l2, (l3[0][:100], l3[1][:100]), P, relu3)       # not a multiple of 64
+
+
+def test_stn_group_rows_path_matches_the_module(hip):
+    """STN_Group.forward_rows (STN3d's conv chain + max as ONE kernel since round 6) against the module's own
+    channel-major forward() -- the reference composition (pointnet2_modules.py:468-537)"""
+    from rfdnet_amd import synthetic
+    from rfdnet_amd.pointnet2_ops.pointnet2_modules import STN_Group
+    stn = STN_Group(radius=1., nsample=1024, use_xyz=False, normalize_xyz=True)
+    synthetic.load_seeded(stn, 11)
+    stn = stn.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    xyz = (torch.rand(1, 20000, 3, device="cuda", generator=g) - 0.5) * 4
+    feats = torch.randn(1, 2, 20000, device="cuda", generator=g)
+    centres = xyz[:, :7].contiguous() + 0.05
+    heading = torch.rand(1, 7, device="cuda", generator=g) * 6.28
+    with torch.no_grad():
+        rows, gf = stn.forward_rows(xyz, feats, centres, heading)            # (7, 1024, 3), (1, 2, 7, 1024)
+        ref, gf2 = stn(xyz, feats, centres, heading)                          # (1, 3, 7, 1024)
+    hip.device_status()
+    assert torch.equal(gf, gf2)
+    want = ref[0].permute(1, 2, 0)                                            # (7, 1024, 3)
+    err = (rows - want).abs().max().item()
+    print("STN_Group rows path vs module: max |d| = %.2e (|x| up to %.2f)" % (err, want.abs().max().item()))
+    assert err < 1e-4 * max(1.0, want.abs().max().item())
 
 
 def test_chain_is_what_the_layerwise_path_computes(hip, monkeypatch):

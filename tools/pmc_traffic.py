@@ -63,11 +63,21 @@ def group_main():
 def main():
     if sys.argv[1] == "--group":
         return group_main()
+    first = None
+    if "--first" in sys.argv:                 # only the first K decoder launches in dispatch order: the SCENES' launches
+        i = sys.argv.index("--first")         # (bench.py's self-check and "alone" launches follow the timed region)
+        first = int(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     d, n_points = sys.argv[1], float(sys.argv[2])
     tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
-    kern = "occ_decode"
-    fetch_kb, nf = collect(os.path.join(d, "fetch"), "FETCH_SIZE", kern)
-    write_kb, nw = collect(os.path.join(d, "write"), "WRITE_SIZE", kern)
+    kern = "occ_decode8" if first else "occ_decode"
+    if first:
+        f_rows = collect_rows(os.path.join(d, "fetch"), "FETCH_SIZE", kern)[:first]
+        w_rows = collect_rows(os.path.join(d, "write"), "WRITE_SIZE", kern)[:first]
+        fetch_kb, nf, write_kb, nw = sum(f_rows), len(f_rows), sum(w_rows), len(w_rows)
+    else:
+        fetch_kb, nf = collect(os.path.join(d, "fetch"), "FETCH_SIZE", kern)
+        write_kb, nw = collect(os.path.join(d, "write"), "WRITE_SIZE", kern)
     fetch_b = fetch_kb * 1024 * 2          # gfx950: wide streaming reads are tallied at half their size
     write_b = write_kb * 1024
     bpq = (fetch_b + write_b) / n_points
