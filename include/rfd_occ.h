@@ -162,6 +162,11 @@ int rfd_mc_classify(int K, int n, float pad_value, double iso, const float *grid
 int rfd_mc_emit(int K, int n, float pad_value, double iso, const float *grids,
                 const unsigned char *code, const int *vblock, const int *tblock,
                 int *vbase, double *verts, int *tris, void *stream);
+/* the same, storing va * vertex + vc (one fma per coordinate): Generator3D.extract_mesh's `v -= 0.5; v -= 1;
+ * v /= n - 1; v = box * (v - 0.5)` (generator.py:163-168) is such a map, applied here instead of in a second pass */
+int rfd_mc_emit_affine(int K, int n, float pad_value, double iso, const float *grids,
+                       const unsigned char *code, const int *vblock, const int *tblock,
+                       int *vbase, double *verts, int *tris, double va, double vc, void *stream);
 
 /* ---- proposal post-processing (net_utils/ap_helper.py:131-264 parse_predictions,
  * net_utils/nms.py:79-118, net_utils/libs.py:128-137: CPU numpy + scipy Delaunay

@@ -173,6 +173,20 @@ int rfd_test_hold_cus(int leave_free_cus, const unsigned *release_flag, int max_
 /* "gfx950" etc. of the code object actually loaded. */
 const char *rfd_build_arch(void);
 
+/* Feature propagation up to its shared MLP, fused (PointnetFPModule.forward, pointnet2_modules.py:383-392 + ThreeNN's
+ * sqrt, pointnet2_utils.py:124-125): out [b][c + cs][n] = cat([three_interpolate(points [b][c][m], idx, w), skip
+ * [b][cs][n]], 1) with w_t = r_t / ((r_0 + r_1) + r_2), r_t = 1 / (sqrt(dist2_t) + 1e-8); dist2 / idx [b][n][3] as
+ * three_nn_kernel_wrapper returns them.  Replaces seven launches (sqrt, add, reciprocal, sum, divide, interpolate, cat). */
+int rfd_three_interpolate_cat(int b, int c, int cs, int m, int n, const float *points, const int *idx,
+                              const float *dist2, const float *skip, float *out, void *stream);
+/* A chain of 1 .. 4 pointwise layers on a channel-major tensor, one kernel (csrc/mlp_cols.hip): x [B][widths[0]][N] ->
+ * y [B][widths[n_layers]][N], layer i = W_i a + b_i (+ ReLU when relu[i]); wt[i] = W_i TRANSPOSED [C_(i-1)][C_i] with an
+ * eval-mode BatchNorm folded in by the caller; exact fp32 (one fma chain per output, bias first, k ascending).
+ * N % 8 == 0, widths <= 1024.  The shared MLPs of PointnetFPModule (pointnet2_modules.py:395-403), VotingModule
+ * (vote_module.py:34-61) and ProposalModule's head (proposal_module.py:85-124): conv + BatchNorm + ReLU launches. */
+int rfd_mlp_cols(int B, int N, int n_layers, const int *widths, const float *const *wt, const float *const *bias,
+                 const int *relu, const float *x, float *y, void *stream);
+
 /* One set-abstraction layer after the ball query, fused: group -> centre-subtract
  * [* (1.0f / radius)] -> concat(xyz first) -> 3 x [1x1 conv + BN(eval) + ReLU] -> max over
  * the nsample neighbours, without materialising the (3+c, m, nsample) tensor.  Replaces

@@ -57,9 +57,12 @@ SIGNATURES = {
     "rfd_gemm_f16x3": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, _i, _i, _i, _i, _i, _f, _i, _f],
     "rfd_mc_classify": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f],
     "rfd_mc_emit": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f, _f, _f, _f],
+    "rfd_mc_emit_affine": [_i, _i, _fl, C.c_double, _f, _f, _f, _f, _f, _f, _f, C.c_double, C.c_double, _f],
     "rfd_mc_blocks": [_i],
     "rfd_chain_pack": [_i, _f, _f, _f, _i, _i, _i, _f, _f],
     "rfd_chain_pool": [_i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f],
+    "rfd_mlp_cols": [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f],
+    "rfd_three_interpolate_cat": [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f],
     "rfd_chain_pack_n": [_i, _i, _f, _f, _f, _i, _i, _i, _f, _f],
     "rfd_chain_pool_n": [_i, _i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f],
     "rfd_head_pack": [_f, _f, _f, _i, _i, _i, _f, _f],

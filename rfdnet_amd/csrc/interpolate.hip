@@ -80,6 +80,35 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(
   out[((size_t)bi * c + l) * n + j] = t;
 }
 
+// Feature propagation up to the shared MLP in ONE kernel (PointnetFPModule.forward, pointnet2_modules.py:383-392):
+//   dist = sqrt(dist2) (ThreeNN.forward, pointnet2_utils.py:124-125);  r_t = 1 / (dist_t + 1e-8);
+//   w_t = r_t / ((r_0 + r_1) + r_2);   out[:c] = three_interpolate(points, idx, w);   out[c:] = skip
+// every step in fp32 with correctly rounded sqrt / divisions, in the order torch evaluates the reference's
+// expressions; the interpolation itself is three_interpolate_kernel's expression.  grid (ceil(n/256), c + cs, b).
+__global__ __launch_bounds__(256) void three_interpolate_cat_kernel(
+    int c, int cs, int m, int n, const float *__restrict__ points, const int *__restrict__ idx,
+    const float *__restrict__ dist2, const float *__restrict__ skip, float *__restrict__ out) {
+  const int bi = blockIdx.z, l = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float *o = out + ((size_t)bi * (c + cs) + l) * n + j;
+  if (l >= c) {                                       // the skip connection's channels: torch.cat([interpolated, skip], 1)
+    *o = skip[((size_t)bi * cs + (l - c)) * n + j];
+    return;
+  }
+  const int *pi = idx + ((size_t)bi * n + j) * 3;
+  const float *pd = dist2 + ((size_t)bi * n + j) * 3;
+  const float r0 = 1.0f / (__builtin_sqrtf(pd[0]) + 1e-8f), r1 = 1.0f / (__builtin_sqrtf(pd[1]) + 1e-8f),
+              r2 = 1.0f / (__builtin_sqrtf(pd[2]) + 1e-8f);
+  const float norm = (r0 + r1) + r2;
+  const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
+  const float *pp = points + ((size_t)bi * c + l) * m;
+  float t = pp[pi[1]] * w1;
+  t = __builtin_fmaf(pp[pi[0]], w0, t);
+  t = __builtin_fmaf(pp[pi[2]], w2, t);
+  *o = t;
+}
+
 __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
     int c, int n, int m, const float *__restrict__ grad_out,
     const int *__restrict__ idx, const float *__restrict__ weight,
@@ -133,6 +162,21 @@ RFD_API int three_interpolate_grad_kernel_wrapper(int b, int c, int n, int m,
                      dim3(ceil_div(n, 256), c, b), dim3(256), 0,
                      (hipStream_t)stream, c, n, m, grad_out, idx, weight,
                      grad_points);
+  RFD_CHECK_LAUNCH();
+  return 0;
+}
+
+// out [b][c + cs][n] = cat([three_interpolate(points [b][c][m], idx, weights(dist2)), skip [b][cs][n]], 1);
+// dist2 / idx [b][n][3] as three_nn_kernel_wrapper returns them (SQUARED distances).  skip may be NULL with cs = 0.
+RFD_API int rfd_three_interpolate_cat(int b, int c, int cs, int m, int n, const float *points, const int *idx,
+                                      const float *dist2, const float *skip, float *out, void *stream) {
+  if (b <= 0 || c + cs <= 0 || n <= 0) return 0;
+  if (c < 0 || cs < 0 || (cs > 0 && !skip)) {
+    rfd_set_error("rfd_three_interpolate_cat: channel counts / skip", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(three_interpolate_cat_kernel, dim3(ceil_div(n, 256), c + cs, b), dim3(256), 0,
+                     (hipStream_t)stream, c, cs, m, n, points, idx, dist2, skip, out);
   RFD_CHECK_LAUNCH();
   return 0;
 }

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(
 __global__ __launch_bounds__(MC_BLOCK) void mc_vertices_kernel(
     int n, float pad, double iso, const float *__restrict__ grids,
     const unsigned char *__restrict__ code, const int *__restrict__ vblock,
-    int *__restrict__ vbase, double *__restrict__ verts) {
+    int *__restrict__ vbase, double *__restrict__ verts, double va, double vc) {
   __shared__ unsigned short owner[MC_RUN * 3];
   __shared__ unsigned short first[MC_RUN];
   __shared__ unsigned char sbits[MC_RUN];
@@ -212,9 +212,11 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_vertices_kernel(
     const double f1 = a == 0 ? fhi : flo, f2 = a == 0 ? flo : fhi;
     const double x = (f2 == f1) ? (x2 + x1) / 2 : (x2 - x1) * (iso - f1) / (f2 - f1) + x1;
     double *o = verts + (size_t)(base + t) * 3;
-    o[0] = a == 0 ? x : (double)P.i;
-    o[1] = a == 1 ? x : (double)P.j;
-    o[2] = a == 2 ? x : (double)P.k;
+    // stored coordinate = va * (padded-grid index coordinate) + vc, ONE rounding (va = 1, vc = 0: the library's plain
+    // output; Generator3D.extract_mesh's four steps of generator.py:163-168 collapse to one such map)
+    o[0] = __builtin_fma(va, a == 0 ? x : (double)P.i, vc);
+    o[1] = __builtin_fma(va, a == 1 ? x : (double)P.j, vc);
+    o[2] = __builtin_fma(va, a == 2 ? x : (double)P.k, vc);
   }
 }
 
@@ -308,18 +310,26 @@ RFD_API int rfd_mc_classify(int K, int n, float pad_value, double iso, const flo
 // arrays.  vbase [K][D^3] i32 scratch (written where a point owns a vertex).  verts [NV][3]
 // f64 (padded-grid index coordinates), tris [NT][3] i32 with vertex indices LOCAL to each
 // proposal.
-RFD_API int rfd_mc_emit(int K, int n, float pad_value, double iso, const float *grids,
-                        const unsigned char *code, const int *vblock, const int *tblock,
-                        int *vbase, double *verts, int *tris, void *stream) {
+// rfd_mc_emit_affine: the stored vertices are va * v + vc (what a caller would otherwise do in a second pass over the
+// 24 B / vertex buffer); rfd_mc_emit = the identity map.
+RFD_API int rfd_mc_emit_affine(int K, int n, float pad_value, double iso, const float *grids,
+                               const unsigned char *code, const int *vblock, const int *tblock,
+                               int *vbase, double *verts, int *tris, double va, double vc, void *stream) {
   if (K <= 0 || n <= 0) return 0;
   int rc = upload_tables();
   if (rc) return rc;
   const dim3 grid((unsigned)rfd_mc_blocks(n), K);
   hipLaunchKernelGGL(mc_vertices_kernel, grid, dim3(MC_BLOCK), 0, (hipStream_t)stream, n,
-                     pad_value, iso, grids, code, vblock, vbase, verts);
+                     pad_value, iso, grids, code, vblock, vbase, verts, va, vc);
   RFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(mc_triangles_kernel, grid, dim3(MC_BLOCK), 0, (hipStream_t)stream, n, code,
                      vblock, tblock, vbase, tris);
   RFD_CHECK_LAUNCH();
   return 0;
+}
+
+RFD_API int rfd_mc_emit(int K, int n, float pad_value, double iso, const float *grids,
+                        const unsigned char *code, const int *vblock, const int *tblock,
+                        int *vbase, double *verts, int *tris, void *stream) {
+  return rfd_mc_emit_affine(K, n, pad_value, iso, grids, code, vblock, tblock, vbase, verts, tris, 1.0, 0.0, stream);
 }

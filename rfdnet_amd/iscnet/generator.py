@@ -205,15 +205,15 @@ class Generator3D(object):
         thr = self.logit_threshold()
         n = grids.shape[1]
         box_size = 1 + self.padding
-        v, f, vend, tend = marching_cubes_batch(grids, thr, pad_value=-1e6, return_flat=True)
         # generator.py:163-168, all four steps: `-= 0.5` ("libmcubes shifts by 0.5" -- the library
         # returns plain index coordinates, so this IS part of the reference's result: its demo
         # meshes sit half a cell low, tests/test_mcubes_golden.py), `-= 1` (padding),
-        # `/= n - 1`, `box * (v - 0.5)` -- once on the buffer holding all K meshes, then split
-        # into views.  One pass over the 24 B/vertex buffer: box * ((v - 1.5) / (n - 1) - 0.5)
-        # = a * v + c (differs from the four-op form by rounding only, ~1e-16)
+        # `/= n - 1`, `box * (v - 0.5)`: box * ((v - 1.5) / (n - 1) - 0.5) = a * v + c, applied by the
+        # emitting kernel itself as one fma per coordinate (differs from the four-op form by rounding
+        # only, ~1e-16; until round 6 a second pass over the 24 B / vertex buffer of all K meshes)
         a = box_size / (n - 1)
-        v = torch.add(torch.tensor(-1.5 * a - 0.5 * box_size, dtype=v.dtype), v, alpha=a)
+        v, f, vend, tend = marching_cubes_batch(grids, thr, pad_value=-1e6, return_flat=True,
+                                                affine=(a, -1.5 * a - 0.5 * box_size))
         self.last_buffers = (v, f, vend, tend)
         return [Mesh(v[vend[k]:vend[k + 1]], f[tend[k]:tend[k + 1]]) for k in range(len(vend) - 1)]
 

@@ -14,12 +14,13 @@ def _call(name, dev, *args):
 
 
 @torch.no_grad()
-def marching_cubes_batch(grids, threshold, pad_value=-1e6, return_flat=False):
+def marching_cubes_batch(grids, threshold, pad_value=-1e6, return_flat=False, affine=None):
     """grids (K,n,n,n) f32 device tensor -> list of K (vertices (nv,3) f64,
     faces (nt,3) i32) device tensors.  Vertex coordinates are in the index
     space of the PADDED grid (original grid point i at i + 1).
     return_flat=True -> (all vertices, all faces, vertex bounds, face bounds):
-    one buffer each for the K meshes, split points as Python lists."""
+    one buffer each for the K meshes, split points as Python lists.
+    affine=(a, c): the stored vertices are a * v + c (one fma per coordinate inside the emitting kernel)."""
     assert grids.is_cuda and grids.dtype == torch.float32 and grids.dim() == 4
     grids = grids.contiguous()
     K, n = grids.shape[0], grids.shape[1]
@@ -45,9 +46,10 @@ def marching_cubes_batch(grids, threshold, pad_value=-1e6, return_flat=False):
     tris = torch.empty(max(nt, 1), 3, dtype=torch.int32, device=dev)
     if nv:
         vbase = torch.empty(K * per, dtype=torch.int32, device=dev)          # scratch
-        _call("rfd_mc_emit", dev, K, n, float(pad_value), float(threshold), grids.data_ptr(),
+        va, vc = (1.0, 0.0) if affine is None else (float(affine[0]), float(affine[1]))
+        _call("rfd_mc_emit_affine", dev, K, n, float(pad_value), float(threshold), grids.data_ptr(),
               code.data_ptr(), base[0].data_ptr(), base[1].data_ptr(), vbase.data_ptr(),
-              verts.data_ptr(), tris.data_ptr())
+              verts.data_ptr(), tris.data_ptr(), va, vc)
     if return_flat:
         return verts[:nv], tris[:nt], vend, tend
     return [(verts[vend[k]:vend[k + 1]], tris[tend[k]:tend[k + 1]]) for k in range(K)]

@@ -74,6 +74,20 @@ class ProposalModule(nn.Module):
             return None
         raise ValueError('Unknown sampling strategy: %s' % self.sampling)
 
+    def _head_fused(self, x):
+        """the 69-channel head (conv1-bn1-ReLU-conv2-bn2-ReLU-conv3, proposal_module.py:85-124) as ONE kernel at
+        inference (csrc/mlp_cols.hip, BatchNorms folded); None when that path does not apply"""
+        from .. import mlp as fused
+        from ..fold_bn import folded
+        if self.training or not x.is_cuda:
+            return None
+        layers = [folded(self.conv1, self.bn1) + (True,), folded(self.conv2, self.bn2) + (True,),
+                  folded(self.conv3) + (False,)]
+        x = x.contiguous()
+        if not fused.usable(x, [x.shape[1]] + [W.shape[0] for W, _, _ in layers]):
+            return None
+        return fused.mlp_cols(x, layers)
+
     def forward(self, xyz, features, end_points, export_proposal_feature=False):
         """xyz (B,K,3) vote positions, features (B,C,K) vote features -> end_points with the
         decoded head (+ the 128-d proposal features on request)."""
@@ -81,8 +95,11 @@ class ProposalModule(nn.Module):
         xyz, features, fps_inds = self.vote_aggregation(xyz, features, picked)
         end_points['aggregated_vote_xyz'] = xyz
         end_points['aggregated_vote_inds'] = fps_inds if picked is None else picked
-        h = features
-        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2)):
-            h = torch.relu(bn(conv(h)))
-        end_points = decode_scores(self.conv3(h), end_points, self.num_heading_bin, self.num_size_cluster)
+        scores = self._head_fused(features)
+        if scores is None:
+            h = features
+            for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2)):
+                h = torch.relu(bn(conv(h)))
+            scores = self.conv3(h)
+        end_points = decode_scores(scores, end_points, self.num_heading_bin, self.num_size_cluster)
         return end_points, (features if export_proposal_feature else None)

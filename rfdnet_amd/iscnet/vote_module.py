@@ -33,15 +33,32 @@ class VotingModule(nn.Module):
         self.in_dim = self.out_dim = d                     # residual connection: widths must agree
         _head(self, (d, d, (3 + d) * self.vote_factor), d)
 
+    def _head_fused(self, x):
+        """conv1-bn1-ReLU-conv2-bn2-ReLU-conv3 as ONE kernel at inference (csrc/mlp_cols.hip; BatchNorms folded),
+        None when that path does not apply (training, CPU, a seed count that is no multiple of 8)"""
+        from .. import mlp as fused
+        from ..fold_bn import folded
+        if self.training or not x.is_cuda:
+            return None
+        layers = [folded(self.conv1, self.bn1) + (True,), folded(self.conv2, self.bn2) + (True,),
+                  folded(self.conv3) + (False,)]
+        x = x.contiguous()
+        if not fused.usable(x, [x.shape[1]] + [W.shape[0] for W, _, _ in layers]):
+            return None
+        return fused.mlp_cols(x, layers)
+
     def forward(self, seed_xyz, seed_features):
         """seed_xyz (B,S,3), seed_features (B,256,S) -> vote_xyz (B,S*vf,3), vote_features
         (B,256,S*vf); vote s*vf + v belongs to seed s."""
         B, S, _ = seed_xyz.shape
         vf, d = self.vote_factor, self.out_dim
-        h = seed_features
-        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2)):
-            h = torch.relu(bn(conv(h)))
-        out = self.conv3(h).view(B, vf, 3 + d, S)                       # [vote][offset | residual][seed]
+        out = self._head_fused(seed_features)
+        if out is None:
+            h = seed_features
+            for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2)):
+                h = torch.relu(bn(conv(h)))
+            out = self.conv3(h)
+        out = out.view(B, vf, 3 + d, S)                                  # [vote][offset | residual][seed]
         offsets = out[:, :, :3].permute(0, 3, 1, 2)                      # (B,S,vf,3)
         vote_xyz = (seed_xyz.unsqueeze(2) + offsets).reshape(B, S * vf, 3)
         feats = seed_features.unsqueeze(1) + out[:, :, 3:]               # (B,vf,d,S)

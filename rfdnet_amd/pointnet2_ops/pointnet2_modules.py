@@ -98,7 +98,32 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = build_shared_mlp(mlp, bn=bn)
 
+    def _fused_layers(self):
+        """the shared MLP as [(W, b, relu)] with the eval-mode BatchNorms folded in, or None (no BatchNorm / training)"""
+        from ..fold_bn import folded
+        mods = list(self.mlp)
+        if self.training or len(mods) % 3 or not mods:
+            return None
+        out = []
+        for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
+            if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and isinstance(act, nn.ReLU)):
+                return None
+            out.append(folded(conv, bn) + (True,))
+        return out
+
     def forward(self, unknown, known, unknow_feats, known_feats):
+        from .. import mlp as fused
+        layers = self._fused_layers() if known is not None and known_feats.is_cuda else None
+        if layers is not None and 1 <= len(layers) <= 4:
+            widths = [known_feats.shape[1] + (0 if unknow_feats is None else unknow_feats.shape[1])] + \
+                [W.shape[0] for W, _, _ in layers]
+            if known_feats.dtype == torch.float32 and fused.fits(unknown.shape[1], widths):
+                # inference: three launches -- three_nn, interpolation with its inverse-distance weights + the skip
+                # concatenation, the whole shared MLP -- instead of twenty-two (csrc/interpolate.hip, csrc/mlp_cols.hip)
+                dist2, idx = pointnet2_utils._ext.three_nn(unknown.contiguous(), known.contiguous())
+                skip = None if unknow_feats is None else unknow_feats.contiguous()
+                x = fused.interpolate_cat(known_feats.contiguous(), idx, dist2, skip)
+                return fused.mlp_cols(x, layers)
         if known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)

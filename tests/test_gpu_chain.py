@@ -72,7 +72,7 @@ def test_chain_with_a_narrower_last_layer(hip, c3, mode, d, relu3, B, P):
     assert out.shape == (B, c3)
     assert (out.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item()) < 2e-5
     with pytest.raises(AssertionError):
-        chain.chain_pool(x, l1, l2, (l3[0][:100], l3[1][:100]), P, relu3)       # not a multiple of 64
+        chain.chain_pool(x, l1, l2, (l3[0][:c3 - 4], l3[1][:c3 - 4]), P, relu3)  # not a multiple of 64
 
 
 def test_stn_group_rows_path_matches_the_module(hip):
