@@ -180,8 +180,9 @@ const char *rfd_build_arch(void);
 int rfd_three_interpolate_cat(int b, int c, int cs, int m, int n, const float *points, const int *idx,
                               const float *dist2, const float *skip, float *out, void *stream);
 /* A chain of 1 .. 4 pointwise layers on a channel-major tensor, one kernel (csrc/mlp_cols.hip): x [B][widths[0]][N] ->
- * y [B][widths[n_layers]][N], layer i = W_i a + b_i (+ ReLU when relu[i]); wt[i] = W_i TRANSPOSED [C_(i-1)][C_i] with an
- * eval-mode BatchNorm folded in by the caller; exact fp32 (one fma chain per output, bias first, k ascending).
+ * y [B][widths[n_layers]][N], layer i = W_i a + b_i (+ ReLU when relu[i]); wt[i] = W_i TRANSPOSED, rows zero padded to a
+ * multiple of four: [C_(i-1)][(C_i + 3) & ~3], 16-byte aligned, with an eval-mode BatchNorm folded in by the caller;
+ * exact fp32 fma arithmetic (the k range of a layer is summed in up to 8 interleaved slices, then bias + slices in order).
  * N % 8 == 0, widths <= 1024.  The shared MLPs of PointnetFPModule (pointnet2_modules.py:395-403), VotingModule
  * (vote_module.py:34-61) and ProposalModule's head (proposal_module.py:85-124): conv + BatchNorm + ReLU launches. */
 int rfd_mlp_cols(int B, int N, int n_layers, const int *widths, const float *const *wt, const float *const *bias,

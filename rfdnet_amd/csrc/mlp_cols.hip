@@ -9,10 +9,13 @@
 // conv, BatchNorm and ReLU of every layer as separate launches of ~4.5 us on ~0.1 GFLOP -- twenty launches for the
 // three heads; the arithmetic is nothing (0.4 GFLOP per scene), the launches and the round trips were the cost.
 //
-// Exact fp32: one fma chain per output, bias first then k ascending (no split precision here: these layers feed
-// vote positions and box parameters).  A workgroup owns MLP_P points of one scene and ALL channels: activations
-// stay in LDS between layers, a thread computes channels t, t + 256, ... for the tile's points, weights are read
-// TRANSPOSED ([C_in][C_out]: consecutive threads = consecutive addresses) from L2.
+// Exact fp32 (no split precision: these layers feed vote positions and box parameters).  A workgroup owns MLP_P
+// points of one scene and ALL channels; activations stay in LDS between layers.  The kernel is bound by how many
+// weight bytes a CU keeps in flight (a first version with one 4-byte load per lane and k ran at ~30 GB/s per CU:
+// 42 us for the 512 -> 256 -> 256 MLP), so a lane owns FOUR consecutive output channels (one 16-byte load of the
+// transposed, 4-padded weight row per k) and the k range is split over the thread groups that many channel quads
+// leave free (256 / quads-rounded-up-to-a-power-of-two slices); the slices' partial sums meet in LDS, where bias,
+// the fixed-order sum over slices and the ReLU finish a layer.
 #include "common.h"
 
 namespace {
@@ -20,12 +23,13 @@ namespace {
 constexpr int MLP_THREADS = 256;
 constexpr int MLP_P = 8;              // points per workgroup
 constexpr int MLP_CMAX = 1024;        // widest layer
+constexpr int MLP_KU = 8;             // k rows fetched per batch and slice
 typedef float mlp4 __attribute__((ext_vector_type(4)));
 
 struct MlpArgs {
   int n_layers, N;
   int width[5];                        // C_0 .. C_L
-  const float *wt[4];                  // [C_{i-1}][C_i]
+  const float *wt[4];                  // [C_{i-1}][pad4(C_i)], zero padded
   const float *bias[4];                // [C_i]
   int relu[4];
   const float *x;
@@ -33,7 +37,8 @@ struct MlpArgs {
 };
 
 __global__ __launch_bounds__(MLP_THREADS) void mlp_cols_kernel(MlpArgs a) {
-  __shared__ __attribute__((aligned(16))) float act[2][MLP_CMAX][MLP_P];
+  __shared__ __attribute__((aligned(16))) float act[2][MLP_CMAX][MLP_P];          // 64 KiB
+  __shared__ __attribute__((aligned(16))) float part[MLP_THREADS][4][MLP_P];      // 32 KiB: [slice x quad][channel][point]
   const int t = threadIdx.x;
   const int n0 = blockIdx.x * MLP_P, b = blockIdx.y;
   const int c0 = a.width[0];
@@ -47,48 +52,77 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_cols_kernel(MlpArgs a) {
   int cur = 0;
   for (int l = 0; l < a.n_layers; ++l) {
     const int cin = a.width[l], cout = a.width[l + 1];
+    const int ldw = (cout + 3) & ~3;                  // padded row length of the transposed weights
     const bool last = l + 1 == a.n_layers;
-    const float *wt = a.wt[l];
-    for (int c = t; c < cout; c += MLP_THREADS) {
-      float acc[MLP_P];
-      const float bv = a.bias[l][c];
+    // output channels in blocks of up to 1024 / ... : quads of this pass, rounded up to a power of two (<= 256)
+    for (int cb = 0; cb < cout; cb += 4 * MLP_THREADS) {        // (one pass for every width <= 1024)
+      const int quads = (min(cout - cb, 4 * MLP_THREADS) + 3) >> 2;
+      int qp = 1;
+      while (qp < quads) qp <<= 1;
+      const int slices = MLP_THREADS / qp;
+      const int q = t & (qp - 1), slice = t / qp;
+      float acc[4][MLP_P];
 #pragma unroll
-      for (int p = 0; p < MLP_P; ++p) acc[p] = bv;
-      const float *w = wt + c;
-#pragma unroll 8
-      for (int k = 0; k < cin; ++k) {
-        const float wv = w[(size_t)k * cout];
-        const mlp4 a0 = *reinterpret_cast<const mlp4 *>(&act[cur][k][0]);
-        const mlp4 a1 = *reinterpret_cast<const mlp4 *>(&act[cur][k][4]);
+      for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          acc[p] = __builtin_fmaf(wv, a0[p], acc[p]);
-          acc[4 + p] = __builtin_fmaf(wv, a1[p], acc[4 + p]);
+        for (int p = 0; p < MLP_P; ++p) acc[ch][p] = 0.f;
+      if (q < quads) {
+        const float *w = a.wt[l] + cb + 4 * q;
+        for (int k0 = slice; k0 < cin; k0 += slices * MLP_KU) {
+          mlp4 wv[MLP_KU], a0[MLP_KU], a1[MLP_KU];
+#pragma unroll
+          for (int j = 0; j < MLP_KU; ++j) {
+            const int k = k0 + j * slices;
+            const int kc = k < cin ? k : cin - 1;                 // past the end: any valid row, masked below
+            wv[j] = *reinterpret_cast<const mlp4 *>(w + (size_t)kc * ldw) * (k < cin ? 1.f : 0.f);
+            a0[j] = *reinterpret_cast<const mlp4 *>(&act[cur][kc][0]);
+            a1[j] = *reinterpret_cast<const mlp4 *>(&act[cur][kc][4]);
+          }
+#pragma unroll
+          for (int j = 0; j < MLP_KU; ++j)
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+              for (int p = 0; p < 4; ++p) {
+                acc[ch][p] = __builtin_fmaf(wv[j][ch], a0[j][p], acc[ch][p]);
+                acc[ch][4 + p] = __builtin_fmaf(wv[j][ch], a1[j][p], acc[ch][4 + p]);
+              }
         }
       }
-      if (a.relu[l]) {
 #pragma unroll
-        for (int p = 0; p < MLP_P; ++p) acc[p] = acc[p] > 0.f ? acc[p] : 0.f;
+      for (int ch = 0; ch < 4; ++ch) {
+        *reinterpret_cast<mlp4 *>(&part[t][ch][0]) = mlp4{acc[ch][0], acc[ch][1], acc[ch][2], acc[ch][3]};
+        *reinterpret_cast<mlp4 *>(&part[t][ch][4]) = mlp4{acc[ch][4], acc[ch][5], acc[ch][6], acc[ch][7]};
       }
-      if (last) {
-        mlp4 *dst = reinterpret_cast<mlp4 *>(a.y + ((size_t)b * cout + c) * a.N + n0);
-        dst[0] = mlp4{acc[0], acc[1], acc[2], acc[3]};
-        dst[1] = mlp4{acc[4], acc[5], acc[6], acc[7]};
-      } else {
-        *reinterpret_cast<mlp4 *>(&act[cur ^ 1][c][0]) = mlp4{acc[0], acc[1], acc[2], acc[3]};
-        *reinterpret_cast<mlp4 *>(&act[cur ^ 1][c][4]) = mlp4{acc[4], acc[5], acc[6], acc[7]};
+      __syncthreads();
+      // finish: thread (channel, point half) adds bias + the slices' partial sums in slice order
+      for (int i = t; i < 4 * quads * 2; i += MLP_THREADS) {
+        const int cl = i >> 1, ph = i & 1;                         // channel within the pass, which 4 points
+        const int c = cb + cl;
+        if (c < cout) {
+          const float bv = a.bias[l][c];
+          mlp4 s = mlp4{bv, bv, bv, bv};
+          for (int sl = 0; sl < slices; ++sl)
+            s += *reinterpret_cast<const mlp4 *>(&part[sl * qp + (cl >> 2)][cl & 3][4 * ph]);
+          if (a.relu[l]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : 0.f;
+          }
+          if (last) *reinterpret_cast<mlp4 *>(a.y + ((size_t)b * cout + c) * a.N + n0 + 4 * ph) = s;
+          else *reinterpret_cast<mlp4 *>(&act[cur ^ 1][c][4 * ph]) = s;
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     cur ^= 1;
   }
 }
 
 }  // namespace
 
-// x [B][widths[0]][N] -> y [B][widths[n_layers]][N] through 1 .. 4 layers; wt[i] = W_i TRANSPOSED ([C_{i-1}][C_i],
-// BatchNorm folded in), bias[i] [C_i], relu[i] != 0: ReLU after layer i.  N % 8 == 0, every width <= 1024, x / y
-// 16-byte aligned.
+// x [B][widths[0]][N] -> y [B][widths[n_layers]][N] through 1 .. 4 layers; wt[i] = W_i TRANSPOSED with its rows zero
+// padded to a multiple of four ([C_{i-1}][(C_i + 3) & ~3], BatchNorm folded in, 16-byte aligned), bias[i] [C_i],
+// relu[i] != 0: ReLU after layer i.  N % 8 == 0, every width <= 1024, x / y 16-byte aligned.
 RFD_API int rfd_mlp_cols(int B, int N, int n_layers, const int *widths, const float *const *wt, const float *const *bias,
                          const int *relu, const float *x, float *y, void *stream) {
   if (B <= 0 || N <= 0) return 0;
@@ -109,6 +143,10 @@ RFD_API int rfd_mlp_cols(int B, int N, int n_layers, const int *widths, const fl
     a.wt[i] = i < n_layers ? wt[i] : nullptr;
     a.bias[i] = i < n_layers ? bias[i] : nullptr;
     a.relu[i] = i < n_layers ? relu[i] : 0;
+    if (i < n_layers && ((uintptr_t)wt[i] & 15)) {
+      rfd_set_error("rfd_mlp_cols: transposed weights must be 16-byte aligned", hipErrorInvalidValue);
+      return (int)hipErrorInvalidValue;
+    }
   }
   hipLaunchKernelGGL(mlp_cols_kernel, dim3(N / MLP_P, B), dim3(MLP_THREADS), 0, (hipStream_t)stream, a);
   RFD_CHECK_LAUNCH();

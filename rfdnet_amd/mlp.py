@@ -24,14 +24,18 @@ def usable(x, widths):
 
 
 def _transposed(W):
-    """(Cout, Cin) -> contiguous (Cin, Cout), cached per parameter version (shared by the host threads)"""
+    """(Cout, Cin) -> contiguous (Cin, pad4(Cout)) with zero padding (the kernel reads a lane's four consecutive
+    output channels with one 16-byte load), cached per parameter version (shared by the host threads)"""
     key = (W.data_ptr(), W._version, tuple(W.shape), str(W.device))
     hit = _wt_cache.get(key)
     if hit is None:
         with _lib.BUILD_LOCK:
             hit = _wt_cache.get(key)
             if hit is None:
-                hit = (W.detach().t().contiguous(), W)        # keep the keyed tensor alive: its address is the key
+                cout, cin = W.shape
+                wt = torch.zeros(cin, (cout + 3) // 4 * 4, dtype=W.dtype, device=W.device)
+                wt[:, :cout] = W.detach().t()
+                hit = (wt, W)                                 # keep the keyed tensor alive: its address is the key
                 if len(_wt_cache) > 256:
                     _wt_cache.clear()
                 _lib.publish(W.device)
