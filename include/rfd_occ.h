@@ -250,7 +250,8 @@ int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *pac
  * a pointer offset of 4096 bytes per channel block.  `sa` is a property of the data: producer and consumer agree on it.
  * rfd_rows_to_frag / rfd_frag_to_rows convert from / to fp32 rows ((hi + lo) 2^-sa is exact).
  * rfd_gemm_f16x3_frag: C_frag = split(relu(A W^T + bias + gbias[m / rows_per_group]) 2^sa), A given as frag rows;
- * M % 256 == 0, N % 256 == 0, K % 128 == 0, rows_per_group % 64 == 0 when gbias / pool_max is given; packed_w from
+ * M % 256 == 0, N % 256 == 0, K % 128 == 0, rows_per_group % 64 == 0 when gbias / pool_max is given (gbias_stride = floats
+ * between its rows, 0 = N: gbias may be a column window of a wider per-group matrix); packed_w from
  * rfd_gemm_pack_w.  C_frag may be NULL with pool_max ([M / rows_per_group][N]: max over the group's rows of the fp32
  * result -- max(0, .) into a zero-initialised pool, the plain max into a -inf-initialised one with pool_signed).
  * Replaces, per ResnetBlockFC of the encoder (layers.py:5-48, 340-392), the ReLU + scale + split that every GEMM
@@ -259,7 +260,7 @@ size_t rfd_frag_bytes(int M, int C);
 int rfd_rows_to_frag(int M, int C, const float *x, int ldx, int relu, int sa, void *out, long rb_stride, void *stream);
 int rfd_frag_to_rows(int M, int C, const void *in, long rb_stride, int sa, float *x, int ldx, void *stream);
 int rfd_gemm_f16x3_frag(int M, int N, int K, const void *A_frag, long a_rb_stride, const void *packed_w,
-                        void *C_frag, long c_rb_stride, const float *bias, const float *gbias,
+                        void *C_frag, long c_rb_stride, const float *bias, const float *gbias, int gbias_stride,
                         int rows_per_group, int sa, int sw, float *pool_max, int pool_signed, void *stream);
 
 /* ---- first layer of the skip-propagation point encoder (csrc/pos_embed.hip) ------------

@@ -71,7 +71,7 @@ SIGNATURES = {
     "rfd_pos_embed_frag": [_i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _i, _f, C.c_long, _i, _f],
     "rfd_rows_to_frag": [_i, _i, _f, _i, _i, _i, _f, C.c_long, _f],
     "rfd_frag_to_rows": [_i, _i, _f, C.c_long, _i, _f, _i, _f],
-    "rfd_gemm_f16x3_frag": [_i, _i, _i, _f, C.c_long, _f, _f, C.c_long, _f, _f, _i, _i, _i, _f, _i, _f],
+    "rfd_gemm_f16x3_frag": [_i, _i, _i, _f, C.c_long, _f, _f, C.c_long, _f, _f, _i, _i, _i, _i, _f, _i, _f],
 }
 _RESTYPES = {
     "rfd_last_error_string": C.c_char_p,

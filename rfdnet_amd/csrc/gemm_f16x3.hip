@@ -1111,13 +1111,15 @@ RFD_API int rfd_frag_to_rows(int M, int C, const void *in, long rb_stride, int s
   return 0;
 }
 
+// gbias_stride: floats between the groups' rows of gbias (0 = N: contiguous; a column window of a wider matrix otherwise).
 // C_frag = split(relu(A W^T + bias + gbias[m / rows_per_group]) 2^sa) with A given as frag rows (already rectified and
 // scaled by 2^sa by ITS producer).  M % 256 == 0, N % 256 == 0, K % 128 == 0, rows_per_group % 64 == 0 when gbias or
 // pool_max is given.  C_frag may be NULL with pool_max (max over the rows of each group of the fp32 result: max(0, .)
 // into a zero-initialised pool, or the plain max into a -inf-initialised one with pool_signed).
 RFD_API int rfd_gemm_f16x3_frag(int M, int N, int K, const void *A_frag, long a_rb_stride, const void *packed_w,
                                 void *C_frag, long c_rb_stride, const float *bias, const float *gbias,
-                                int rows_per_group, int sa, int sw, float *pool_max, int pool_signed, void *stream) {
+                                int gbias_stride, int rows_per_group, int sa, int sw, float *pool_max, int pool_signed,
+                                void *stream) {
   if (M <= 0) return 0;
   if (!C_frag && !pool_max) {
     rfd_set_error("rfd_gemm_f16x3_frag: C_frag == NULL without pool_max", hipErrorInvalidValue);
@@ -1126,7 +1128,7 @@ RFD_API int rfd_gemm_f16x3_frag(int M, int N, int K, const void *A_frag, long a_
   const int rpg = rows_per_group > 0 ? rows_per_group : 1;
   if (M % RM || N % RN || K % 128 || N > RFD_ZEROS_FLOATS || ((gbias || pool_max) && rpg % 64) || (a_rb_stride & 15) ||
       (c_rb_stride & 15) || ((uintptr_t)A_frag & 15) || ((uintptr_t)C_frag & 15) || ((uintptr_t)bias & 15) ||
-      ((uintptr_t)gbias & 15)) {
+      ((uintptr_t)gbias & 15) || (gbias_stride & 3)) {
     rfd_set_error("rfd_gemm_f16x3_frag: need M % 256, N % 256, K % 128, rows_per_group % 64, 16-byte aligned operands",
                   hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
@@ -1146,7 +1148,7 @@ RFD_API int rfd_gemm_f16x3_frag(int M, int N, int K, const void *A_frag, long a_
   g.Af = (const unsigned char *)A_frag; g.af_stride = a_rb_stride;
   g.Cf = (unsigned char *)C_frag; g.cf_stride = c_rb_stride;
   g.zeros = ws->zeros;
-  g.cb1 = gbias; g.cb1_stride = gbias ? N : 0;
+  g.cb1 = gbias; g.cb1_stride = gbias ? (gbias_stride > 0 ? gbias_stride : N) : 0;
   g.cb2 = bias; g.cb2_stride = 0;
   // persistent: one workgroup per CU (144 KiB of LDS each), a multiple of the n tiles so that a workgroup keeps ONE W
   // stream, and of 8 x n tiles when possible (XCD-aware tile lists, see the kernel)

@@ -152,6 +152,7 @@ def linear_frag(a, weight, bias=None, gbias=None, rows_per_group=1, out=None, po
     M, K = a.shape[0] * 32, a.shape[1] * 32
     N = weight.shape[0]
     sa = SA if sa is None else sa
+    assert gbias is None or (gbias.stride(1) == 1 and gbias.shape[1] == N), "gbias: (groups, N) rows, row stride allowed"
     assert weight.shape[1] == K and frag_usable(M, N, K, rows_per_group if (gbias is not None or pool is not None) else 64)
     packed, sw, _ = _packed(weight)
     if not store:
@@ -165,6 +166,7 @@ def linear_frag(a, weight, bias=None, gbias=None, rows_per_group=1, out=None, po
         rc = _lib.lib().rfd_gemm_f16x3_frag(
             M, N, K, aptr, astride, packed.data_ptr(), cptr, cstride,
             bias.data_ptr() if bias is not None else None, gbias.data_ptr() if gbias is not None else None,
+            int(gbias.stride(0)) if gbias is not None else 0,
             int(rows_per_group), int(sa), sw, pool.data_ptr() if pool is not None else None, int(pool_signed),
             _lib.current_stream())
     _lib.check(rc, "rfd_gemm_f16x3_frag")

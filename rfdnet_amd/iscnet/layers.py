@@ -97,7 +97,7 @@ class ResnetPointnet(nn.Module):
             cat[:, h:] = x2
         pooled, width = None, 3 * h
         for i in range(5):
-            blk, w_first, w_second, w0_pool, ws_pool = weights(i)
+            blk, w_first, w_second, w0_pool, ws_pool = weights(i)[:5]
             g0 = gs = None
             if i:
                 g0 = F.linear(pooled, w0_pool, blk.fc_0.bias)                # once per proposal
@@ -134,7 +134,10 @@ class ResnetPointnet(nn.Module):
                     first = (w0 if wide else w0[:, :h]).contiguous()
                     second = torch.cat([blk.fc_1.weight.detach(), ws if wide else ws[:, :h]], 1).contiguous()
                     entry = (key, first, second, None if wide else w0[:, h:].contiguous(),
-                             None if wide else ws[:, h:].contiguous())
+                             None if wide else ws[:, h:].contiguous(),
+                             # both pooled-half matrices and both biases stacked: ONE small GEMM per block
+                             None if wide else torch.cat([w0[:, h:], ws[:, h:]], 0).contiguous(),
+                             None if wide else torch.cat([blk.fc_0.bias.detach(), blk.fc_1.bias.detach()]).contiguous())
                     _lib.publish(second.device)
                     c[i] = entry
         return (blk,) + c[i][1:]
@@ -167,17 +170,18 @@ class ResnetPointnet(nn.Module):
         hb = h // 32
         M = B * T
         pooled = None
+        pools = torch.zeros(5, B, h, device=cat.device, dtype=torch.float32)       # the five blocks' max-pool targets
         for i in range(5):
-            blk, w_first, w_second, w0_pool, ws_pool = self._block_weights(i)
+            blk, w_first, w_second, _, _, w_pool, b_pool = self._block_weights(i)
             g0 = gs = None
             if i:
-                g0 = F.linear(pooled, w0_pool, blk.fc_0.bias)                # once per proposal
-                gs = F.linear(pooled, ws_pool, blk.fc_1.bias)
+                g = torch.addmm(b_pool, pooled, w_pool.t())                  # (B, 2h) once per proposal: [fc_0 | shortcut]
+                g0, gs = g[:, :h], g[:, h:]                                  # column windows (row stride 2h)
             gemm.linear_frag(cat[:, hb:], w_first, bias=None if i else blk.fc_0.bias, gbias=g0, rows_per_group=T,
                              out=cat[:, :hb], sa=sa)
             last = i == 4
             nxt = None if last else gemm.frag_empty(M, 2 * h, cat.device)
-            pooled = torch.zeros(B, h, device=cat.device, dtype=torch.float32)
+            pooled = pools[i]
             gemm.linear_frag(cat, w_second, bias=None if i else blk.fc_1.bias, gbias=gs, rows_per_group=T,
                              out=None if last else nxt[:, hb:], pool=pooled, store=not last, sa=sa)
             cat = nxt

@@ -407,7 +407,7 @@ def test_gemm_frag_matches_fp64_reference(hip, M, N, K, T):
     x = torch.randn(M, K, device="cuda", generator=g) * 2.0
     w = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / np.sqrt(K)
     bias = torch.randn(N, device="cuda", generator=g)
-    gb = torch.randn(M // T, N, device="cuda", generator=g)
+    gb = torch.randn(M // T, N + 64, device="cuda", generator=g)[:, 32:32 + N]     # a column window: row stride N + 64
     # A = a channel window of a wider frag buffer ([junk | A]); C = a window of another one
     abuf = gemm.frag_empty(M, K + 64, "cuda")
     abuf.view(torch.int16).fill_(0x7c00)                              # f16 inf: any read outside the window poisons
