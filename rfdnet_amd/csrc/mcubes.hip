@@ -115,74 +115,35 @@ __device__ __forceinline__ unsigned edge_bits(unsigned ci) {
 // code[point] = cube index of the cell whose FAR corner is the point, over the padded lattice
 // extended by one more virtual padding layer (cells hanging over the near faces see only
 // padding: index 255, no triangles, no edges -- the same result as "no such cell").
-// A workgroup owns a run of MC_RUN consecutive points (the unit of the two-level scan).
-//
-// Round 6: the first version loaded the 8 corners of every point with clamped, selected addresses -- ~100 VALU
-// instructions per point, 77 M points per scene: instruction-bound at 1.2 TB/s.  A lattice point's ONE bit
-// "value <= iso" is what all eight cells around it need, so the workgroup now
-//   A. turns the lattice rows its run touches (rows r and r - 1 of planes i and i - 1: two runs of ~18 rows at
-//      D = 67) into bit rows in LDS -- one coalesced load, one compare and one ballot per 64 points; everything
-//      outside the interior [1, D - 2]^3 is padding = below the iso level = 1, which also covers the virtual layer
-//      and the rows a linear "r - 1" / "r - D" wraps into (they are boundary rows: all ones);
-//   B. assembles a point's cube index from four 2-bit windows (rows (i, j), (i, j-1), (i-1, j), (i-1, j-1) at
-//      k - 1, k): four LDS reads and ~25 ALU instructions per point.
-constexpr int MC_BITS_WORDS = 1024;          // per plane: (1024 / D + 3) rows x ((D + 32) / 32 + 1) words <= 700
-
+// A workgroup owns a run of MC_RUN consecutive points, four per thread: the 32 corner loads
+// of a thread are independent and the per-run scan covers 4x the points (these passes were
+// bound by workgroup latency x rounds, not by bandwidth).  In the emit kernels thread t owns
+// the points 4t .. 4t+3 so that the scan order is the point order.
 __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(
     int n, float pad, double iso, const float *__restrict__ grids,
     unsigned char *__restrict__ code, int *__restrict__ vsum, int *__restrict__ tsum) {
-  __shared__ unsigned bits[2][MC_BITS_WORDS];                  // [plane i / plane i-1][row slot][word]
   const int D = n + 2;
   const unsigned per = (unsigned)D * D * D;
   const int kp = blockIdx.y;
   const float thr = float_floor(iso);
-  const bool pad_below = pad <= thr;                            // the padding value's own bit (-1e6: true)
-  const unsigned e0 = blockIdx.x * MC_RUN;
-  const float *g = grids + (size_t)kp * n * n * n;
-  const int r0 = (int)(e0 / D);
-  const unsigned last = min(e0 + MC_RUN, per) - 1;
-  const int r1 = (int)(last / D);
-  const int nrows = r1 - r0 + 2;                                // slots 0 .. nrows-1 <-> rows r0-1 .. r1 (plane i)
-  const int wpr = (D + 32) / 32 + 1;                            // words per bit row (bit b <-> k = b - 1) + one spare
-  const int nseg = (D + 1 + 63) / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // ---- A: bit rows
-  for (int u = wave; u < 2 * nrows * nseg; u += MC_BLOCK / 64) {
-    const int seg = u % nseg, slot = (u / nseg) % nrows, plane = u / (nseg * nrows);
-    const int q = r0 - 1 + slot - (plane ? D : 0);              // linear row index (i D + j)
-    const int qi = q >= 0 ? q / D : -1, qj = q >= 0 ? q - qi * D : -1;
-    const bool row_in = qi >= 1 && qi <= D - 2 && qj >= 1 && qj <= D - 2;
-    const int k = seg * 64 + lane - 1;
-    bool below = pad_below;
-    if (row_in && k >= 1 && k <= D - 2) below = g[(unsigned)(((qi - 1) * n + (qj - 1)) * n + (k - 1))] <= thr;
-    const unsigned long long m = __ballot(below);
-    if (lane == 0) {
-      unsigned *w = &bits[plane][slot * wpr + 2 * seg];
-      w[0] = (unsigned)m;
-      if (2 * seg + 1 < wpr) w[1] = (unsigned)(m >> 32);
-      if (seg == nseg - 1 && 2 * seg + 2 < wpr) w[2] = pad_below ? 0xffffffffu : 0u;   // the spare word(s)
-    }
-  }
-  __syncthreads();
-  // ---- B: cube indices; lanes take consecutive points (coalesced byte stores), four per thread
+  // only the run TOTALS are needed here, so lanes take consecutive points (coalesced loads)
+  const unsigned e = blockIdx.x * MC_RUN + threadIdx.x;
+  GridView G{grids + (size_t)kp * n * n * n, n, D, pad};
+  // Bourke corner numbering
+  const int cx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, cy[8] = {0, 0, 1, 1, 0, 0, 1, 1},
+            cz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
   int cnt = 0;
 #pragma unroll
   for (int p = 0; p < MC_PTS; ++p) {
-    const unsigned ep = e0 + threadIdx.x + p * MC_BLOCK;
+    const unsigned ep = e + p * MC_BLOCK;
     if (ep < per) {
-      const int r = (int)(ep / D), k = (int)(ep - (unsigned)r * D);
-      const int a = r - r0 + 1;                                 // this row's slot; row r - 1 = slot a - 1
-      const int wi = k >> 5, sh = k & 31;
-      // 2-bit window {lattice k - 1, lattice k} = bits k, k + 1 of a row
-      auto win = [&](int plane, int slot) -> unsigned {
-        const unsigned *w = &bits[plane][slot * wpr + wi];
-        const unsigned long long v = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
-        return (unsigned)(v >> sh) & 3u;
-      };
-      const unsigned a0 = win(0, a), a1 = win(0, a - 1), b0 = win(1, a), b1 = win(1, a - 1);
-      // Bourke corners: c0 (i-1,j-1,k-1) c1 (i,j-1,k-1) c2 (i,j,k-1) c3 (i-1,j,k-1), c4..c7 the same at k
-      const unsigned ci = (b1 & 1u) | ((a1 & 1u) << 1) | ((a0 & 1u) << 2) | ((b0 & 1u) << 3) |
-                          ((b1 >> 1) << 4) | ((a1 >> 1) << 5) | ((a0 >> 1) << 6) | ((b0 >> 1) << 7);
+      const Point P(ep, D);
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = G.at(P.i - 1 + cx[c], P.j - 1 + cy[c], P.k - 1 + cz[c]);
+      unsigned ci = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ci |= (v[c] <= thr ? 1u : 0u) << c;
       code[(size_t)kp * per + ep] = (unsigned char)ci;
       cnt += __popc(edge_bits(ci)) | ((int)c_ntri[ci] << 16);
     }
