@@ -5,7 +5,7 @@ timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest.tx
 timeout 60 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_headline.json 2> $O/bench_headline.err
 timeout 300 python bench.py --config stress --steps 3 --warmup 1 > $O/bench_stress.json 2> $O/bench_stress.err
-timeout 400 python bench.py --config mise128 --steps 4 --warmup 1 > $O/bench_mise128.json 2> $O/bench_mise128.err
+timeout 600 python bench.py --config mise128 --steps 12 --warmup 2 > $O/bench_mise128.json 2> $O/bench_mise128.err
 timeout 300 python bench.py --config dense32 --steps 6 --warmup 2 > $O/bench_dense32.json 2> $O/bench_dense32.err
 timeout 300 python bench.py --config demo --steps 40 --warmup 5 > $O/bench_demo.json 2> $O/bench_demo.err
 python - <<P
@@ -71,13 +71,14 @@ cd $R
 python - <<P > $O/npoints.txt
 import json
 d = json.loads(open("$O/bench_pmc_fetch.json").read().strip().splitlines()[-1])
-print(int(3 * d["config"]["queries_per_scene"] + 5 * 8192))
+print(int(3 * d["config"]["queries_per_scene"]))        # the three scenes' nine launches (pmc_traffic.py --first 9)
 P
-python tools/pmc_traffic.py $O/traffic $(cat $O/npoints.txt) r06 > $O/decoder_traffic.txt 2>&1; cat $O/decoder_traffic.txt
+python tools/pmc_traffic.py --first 9 $O/traffic $(cat $O/npoints.txt) r06 > $O/decoder_traffic.txt 2>&1; cat $O/decoder_traffic.txt
 python tools/pmc_sq.py $O/sq3 "occ_decode8_kernelILi3E" --json f16x3 "profiles/r06_decoder8_pmc.txt (rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES ... over tools/dec_only.py 3 / 1, round 6 final call; busy = MFMA_BUSY / (4 x WAVE_CYCLES / 2), tools/pmc_sq.py)" > $O/decoder8_pmc_f16x3.txt 2>&1; cat $O/decoder8_pmc_f16x3.txt
 python tools/pmc_sq.py $O/sq1 "occ_decode8_kernelILi1E" --json f16x1 "profiles/r06_decoder8_pmc.txt (rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES ... over tools/dec_only.py 3 / 1, round 6 final call; busy = MFMA_BUSY / (4 x WAVE_CYCLES / 2), tools/pmc_sq.py)" > $O/decoder8_pmc_f16x1.txt 2>&1; cat $O/decoder8_pmc_f16x1.txt
 python tools/pmc_sq.py $O/sqg "gemm_rowsf_kernel" > $O/gemm_rowsf_pmc.txt 2>&1; cat $O/gemm_rowsf_pmc.txt
 python tools/pmc_sq.py $O/sqg "gemm_rows8_kernel" > $O/gemm_rows8_pmc.txt 2>&1; cat $O/gemm_rows8_pmc.txt
 cp profiles/decoder_traffic.json profiles/decoder_mfma_busy.json $O/ 2>/dev/null
 rm -rf $O/traffic $O/sq3 $O/sq1 $O/sqg
+if [ -d .r05tree ]; then bash tools/ab/r06_ab_r05.sh > $O/ab_r05.txt 2>&1; cat $O/ab_r05.txt | cut -c1-60; fi
 du -sh $O
