@@ -397,7 +397,10 @@ def test_frag_rows_round_trip_and_layout(hip):
     assert (gemm.frag_to_rows(gemm.rows_to_frag(x, sa=sa, relu=False), sa=sa) - x).abs().max().item() <= 2.0 ** -20 * 16
 
 
-@pytest.mark.parametrize("M,N,K,T", [(256, 256, 128, 64), (512, 512, 384, 128), (2048, 512, 1024, 1024)])
+@pytest.mark.parametrize("M,N,K,T", [(256, 256, 128, 64), (512, 512, 384, 128), (2048, 512, 1024, 1024),
+                                     # tile-list shapes of the persistent kernel: 9 m tiles (no XCD-aware list), three and
+                                     # four n tiles (240 / 256 workgroups), more tiles than workgroups (3 tiles per workgroup)
+                                     (2304, 768, 256, 256), (4096, 1024, 128, 512), (98304, 512, 128, 1024)])
 def test_gemm_frag_matches_fp64_reference(hip, M, N, K, T):
     """rfd_gemm_f16x3_frag against fp64 on the values the frag input REALLY holds: stored output, fused pool,
     pool-only launch, channel windows on both sides -- fp32-class bounds, as for the fp32-rows kernels"""
