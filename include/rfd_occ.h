@@ -240,6 +240,18 @@ int rfd_gemm_f16x3(int M, int N, int K, const float *A, int lda, const void *pac
                    int rows_per_group, const float *R, int ldr, int relu_in, int relu_out,
                    int sa, int sw, float *pool_max, int pool_signed, void *stream);
 
+/* ---- small elementwise passes (csrc/small_ops.hip) -------------------------------------------------------------------
+ * rfd_occ_fold_rows: DecoderCBatchNorm's per-proposal table (layers.py:226-242 folded: rfdnet_amd/occ_fold.py) from the
+ * stacked gamma / beta products gb [K][2L][H]: scale = gb[k][l] / sqrtv[l], shift = gb[k][L+l] - mean[l] scale,
+ * table[k][1+2l] = scale smul[l], table[k][2+2l] = (shift + scale extra[l]) tmul[l], table[k][0] = row0[k] (row0_stride
+ * = H, or 0 for one shared row); every operation rounded on its own (bit-identical to the torch composition).
+ * rfd_rows3_rotate_z / rfd_rows3_affine: STN_Group's two point transforms on rows [G][P][3] (pointnet2_modules.py:517-527,
+ * :452-466): rotation by the group's (cos, sin) about z; the learned 3 x 4 affine A [G][3][4]. */
+int rfd_occ_fold_rows(int K, int L, int H, const float *gb, const float *sqrtv, const float *mean, const float *extra,
+                      const float *smul, const float *tmul, const float *row0, int row0_stride, float *table, void *stream);
+int rfd_rows3_rotate_z(int G, int P, const float *rows, const float *cs, float *out, void *stream);
+int rfd_rows3_affine(int G, int P, const float *rows, const float *A, float *out, void *stream);
+
 /* ---- fragment-ordered split activations ("frag rows", csrc/gemm_f16x3.hip) --------------------------------------
  * Every consumer of an encoder activation rectifies it (layers.py:27,38-46: the in-place ReLU), so a producer can
  * store relu(x) 2^sa ONCE, already split into f16 (hi, lo) -- the same 4 bytes per element as fp32 -- in the operand

@@ -61,6 +61,9 @@ SIGNATURES = {
     "rfd_mc_blocks": [_i],
     "rfd_chain_pack": [_i, _f, _f, _f, _i, _i, _i, _f, _f],
     "rfd_chain_pool": [_i, _i, _i, _i, _f, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f],
+    "rfd_occ_fold_rows": [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f],
+    "rfd_rows3_rotate_z": [_i, _i, _f, _f, _f, _f],
+    "rfd_rows3_affine": [_i, _i, _f, _f, _f, _f],
     "rfd_mlp_cols": [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f],
     "rfd_three_interpolate_cat": [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f],
     "rfd_chain_pack_n": [_i, _i, _f, _f, _f, _i, _i, _i, _f, _f],

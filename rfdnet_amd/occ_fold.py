@@ -146,6 +146,24 @@ def fold_table_stacked(k, z, c):
     K = c.shape[0]
     L = k["mean"].shape[0]
     gb = torch.addmm(k["b"], c, k["w"].t()).view(K, 2 * L, HIDDEN)
+    if c.is_cuda and c.dtype == torch.float32 and not torch.is_grad_enabled():
+        # the elementwise part as ONE kernel (csrc/small_ops.hip rfd_occ_fold_rows): same operations, same order, every
+        # one rounded on its own -- the table is bit-identical to the torch composition below (nine launches)
+        from . import _lib
+        if k["fc_z_w"] is not None and z.shape[1] > 0:
+            row0 = (k["fc_p_b"][None, :] + torch.addmm(k["fc_z_b"], z, k["fc_z_w"].t())) * k["row0_mul"]
+            stride = HIDDEN
+        else:
+            row0 = (k["fc_p_b"] * k["row0_mul"])[None, :].contiguous()
+            stride = 0
+        table = torch.empty(K, TABLE_ROWS, HIDDEN, device=c.device, dtype=c.dtype)
+        smul, tmul = k["smul"].reshape(-1), k["tmul"].reshape(-1)
+        with torch.cuda.device(c.device):
+            rc = _lib.lib().rfd_occ_fold_rows(K, L, HIDDEN, gb.data_ptr(), k["sqrtv"].data_ptr(), k["mean"].data_ptr(),
+                                              k["extra"].data_ptr(), smul.data_ptr(), tmul.data_ptr(), row0.data_ptr(),
+                                              stride, table.data_ptr(), _lib.current_stream())
+        _lib.check(rc, "rfd_occ_fold_rows")
+        return table, k["fc_p_w"]
     scale = gb[:, :L] / k["sqrtv"]
     shift = gb[:, L:] - k["mean"] * scale
     table = torch.empty(K, TABLE_ROWS, HIDDEN, device=c.device, dtype=c.dtype)

@@ -233,6 +233,22 @@ class STN_Group(nn.Module):
         B, K = orientations.size()
         P = grouped_xyz.shape[3]
         rows = grouped_xyz.permute(0, 2, 3, 1).reshape(B * K, P, 3)
+        if rows.is_cuda and rows.dtype == torch.float32 and not torch.is_grad_enabled():
+            # the two point transforms as one kernel each (csrc/small_ops.hip) instead of a zero-filled rotation
+            # matrix assembled by five indexed stores + bmm, and bmm + add
+            from .. import _lib
+            rows = rows.contiguous()
+            cs = torch.stack([torch.cos(orientations).view(-1), torch.sin(orientations).view(-1)], 1).contiguous()
+            rot = torch.empty_like(rows)
+            with torch.cuda.device(rows.device):
+                _lib.check(_lib.lib().rfd_rows3_rotate_z(B * K, P, rows.data_ptr(), cs.data_ptr(), rot.data_ptr(),
+                                                          _lib.current_stream()), "rfd_rows3_rotate_z")
+            A = _stn3d_affine_rows(self.stn3d, rot).contiguous()
+            out = torch.empty_like(rows)
+            with torch.cuda.device(rows.device):
+                _lib.check(_lib.lib().rfd_rows3_affine(B * K, P, rot.data_ptr(), A.data_ptr(), out.data_ptr(),
+                                                        _lib.current_stream()), "rfd_rows3_affine")
+            return out, grouped_features
         cos, sin = torch.cos(orientations).view(-1), torch.sin(orientations).view(-1)
         rot_t = torch.zeros(B * K, 3, 3, device=rows.device, dtype=rows.dtype)   # transpose of the rotation
         rot_t[:, 0, 0] = cos

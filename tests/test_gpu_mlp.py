@@ -83,3 +83,45 @@ def test_fp_vote_proposal_modules_fused_against_their_torch_paths(hip):
         d = (a - b).abs().max().item()
         assert d < 2e-5 * max(1.0, b.abs().max().item()), (k, d)
     assert torch.equal(fast['aggregated_vote_inds'], slow['aggregated_vote_inds'])
+
+
+def test_fold_rows_kernel_is_bit_identical_to_the_torch_composition(hip):
+    """rfd_occ_fold_rows (the decoder's per-proposal table, one launch) against occ_fold.fold_table_stacked's own
+    torch expressions (the path taken under autograd): the same operations in the same order -> the same bits"""
+    from rfdnet_amd.iscnet.occ_decoder import DecoderCBatchNorm
+    from rfdnet_amd import occ_fold
+    dec = DecoderCBatchNorm(dim=3, z_dim=32, c_dim=512, hidden_size=256)
+    synthetic.load_seeded(dec, 3)
+    dec = dec.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for K in (1, 13, 256):
+        c = torch.randn(K, 512, device="cuda", generator=g)
+        for z in (torch.zeros(K, 32, device="cuda"), torch.randn(K, 32, device="cuda", generator=g)):
+            with torch.no_grad():
+                t_fast, w_fast = dec.fold(z, c)
+            consts = dec._fold_cache[1]
+            with torch.enable_grad():
+                t_slow, w_slow = occ_fold.fold_table_stacked(consts, z, c)
+            assert t_fast.shape == (K, 23, 256)
+            assert torch.equal(t_fast, t_slow.detach()) and torch.equal(w_fast, w_slow)
+    hip.device_status()
+
+
+def test_rows3_transforms_match_bmm(hip):
+    from rfdnet_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(6)
+    G, P = 7, 1024
+    rows = torch.randn(G, P, 3, device="cuda", generator=g)
+    ang = torch.rand(G, device="cuda", generator=g) * 6.28
+    cs = torch.stack([torch.cos(ang), torch.sin(ang)], 1).contiguous()
+    out = torch.empty_like(rows)
+    _lib.check(_lib.lib().rfd_rows3_rotate_z(G, P, rows.data_ptr(), cs.data_ptr(), out.data_ptr(), _lib.current_stream()), "rot")
+    rot_t = torch.zeros(G, 3, 3, device="cuda", dtype=torch.float64)
+    rot_t[:, 0, 0] = cs[:, 0]; rot_t[:, 1, 0] = cs[:, 1]; rot_t[:, 0, 1] = -cs[:, 1]; rot_t[:, 1, 1] = cs[:, 0]; rot_t[:, 2, 2] = 1
+    assert (out.double() - torch.bmm(rows.double(), rot_t)).abs().max().item() < 1e-6
+    A = torch.randn(G, 3, 4, device="cuda", generator=g)
+    out2 = torch.empty_like(rows)
+    _lib.check(_lib.lib().rfd_rows3_affine(G, P, rows.data_ptr(), A.data_ptr(), out2.data_ptr(), _lib.current_stream()), "aff")
+    want = torch.bmm(rows.double(), A[:, :, :3].double().transpose(1, 2)) + A[:, :, 3].double().unsqueeze(1)
+    assert (out2.double() - want).abs().max().item() < 2e-6
+    hip.device_status()
