@@ -216,6 +216,12 @@ int rfd_occ_chunk_range(int k, int n_tiles, int n_workgroups, int *begin, int *e
  * (1..255): NOT persistent, one workgroup per chunk of at most c tiles.  Initial values come ONCE from the environment
  * (RFD_DECODER_STATIC, RFD_DECODER_CUS, RFD_DECODER_CHUNK); nothing reads the environment on the launch path. */
 int rfd_occ_set_launch_shape(int static_partition, int cus, int chunk_cap);
+/* Tail launches (csrc/occ_decoder_tail.hip): a decode of at most n_tiles tiles (default 384; RFD_DECODER_TAIL_TILES
+ * once at start-up) runs on a one-wave, no-LDS kernel that can start on a CU other kernels are using, instead of waiting
+ * for empty CUs -- the last MISE rounds of generator.py:99-117's loop, a few thousand points per scene.  Logits bit-identical
+ * to the main kernel's; 16-slot groups that are all padding are skipped.  n_tiles = 0: never; < 0: leave unchanged.
+ * Returns the previous setting. */
+int rfd_occ_set_tail_tiles(int n_tiles);
 /* The same schedule with no chunk larger than max_chunk tiles (max_chunk = 0: uncapped) -- the shape of the
  * one-workgroup-per-chunk launch (rfd_occ_set_launch_shape's chunk_cap); *n_chunks (optional) = number of non-empty chunks = its grid. */
 int rfd_occ_chunk_range_capped(int k, int n_tiles, int n_workgroups, int max_chunk, int *begin, int *end,

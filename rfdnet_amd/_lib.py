@@ -39,6 +39,7 @@ SIGNATURES = {
     "rfd_occ_chunk_range": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "rfd_occ_chunk_range_capped": [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "rfd_occ_set_launch_shape": [_i, _i, _i],
+    "rfd_occ_set_tail_tiles": [_i],
     "rfd_fps_set_timeout_ms": [_i],
     "rfd_fps_set_geometry": [_i],
     "rfd_test_hold_cus": [_i, _f, _i, _f],

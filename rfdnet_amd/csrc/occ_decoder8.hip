@@ -569,14 +569,24 @@ RFD_API int rfd_occ_pack_weights_w8(const float *fc0_w, const float *fc1_w, cons
 // workgroup; cus = n: a persistent grid of n < num_cu workgroups; chunk_cap = c (1..255): NOT persistent, one
 // workgroup per chunk of at most c tiles.  Initialised ONCE from RFD_DECODER_STATIC / RFD_DECODER_CUS /
 // RFD_DECODER_CHUNK (no getenv on the launch path), changed at run time through rfd_occ_set_launch_shape.
+//
+// tail_tiles = n: a launch of at most n tiles (and the default shape otherwise) goes to the one-wave, no-LDS kernel of
+// occ_decoder_tail.hip, which does not need an empty CU to start (bit-identical logits); 0 = never.  RFD_DECODER_TAIL_TILES /
+// rfd_occ_set_tail_tiles.
+int rfd_occ_tail_launch(int n_tiles, const float *pts, const int *tile_prop, const int *tile_src, const void *packed,
+                        const float *fc_p_w, const float *table, const float *fc_out_w, float fc_out_b, float *logits,
+                        unsigned *status, const int *lin, float *values, unsigned char *pstate, size_t n_per, int mode,
+                        hipStream_t stream);
 namespace {
+constexpr int TAIL_TILES_DEFAULT = 384;
 struct LaunchShape {
-  std::atomic<int> static_partition, cus, chunk_cap;
+  std::atomic<int> static_partition, cus, chunk_cap, tail_tiles;
   LaunchShape() {
     const char *e;
     static_partition.store((e = getenv("RFD_DECODER_STATIC")) ? (atoi(e) != 0) : 0);
     cus.store((e = getenv("RFD_DECODER_CUS")) ? atoi(e) : 0);
     chunk_cap.store((e = getenv("RFD_DECODER_CHUNK")) ? atoi(e) : 0);
+    tail_tiles.store((e = getenv("RFD_DECODER_TAIL_TILES")) ? atoi(e) : TAIL_TILES_DEFAULT);
   }
 };
 LaunchShape &launch_shape() {
@@ -592,6 +602,15 @@ RFD_API int rfd_occ_set_launch_shape(int static_partition, int cus, int chunk_ca
   if (cus >= 0) ls.cus.store(cus);
   if (chunk_cap >= 0) ls.chunk_cap.store(chunk_cap > 255 ? 255 : chunk_cap);
   return 0;
+}
+
+// Launches of at most n_tiles tiles use the small-footprint kernel (0 = never); n_tiles < 0 leaves the setting.  Returns
+// the previous value.
+RFD_API int rfd_occ_set_tail_tiles(int n_tiles) {
+  LaunchShape &ls = launch_shape();
+  const int old = ls.tail_tiles.load();
+  if (n_tiles >= 0) ls.tail_tiles.store(n_tiles);
+  return old;
 }
 
 static int decode_w8(int n_tiles, const float *pts, const int *tile_prop, const int *tile_src,
@@ -610,6 +629,9 @@ static int decode_w8(int n_tiles, const float *pts, const int *tile_prop, const 
   const bool static_part = ls.static_partition.load(std::memory_order_relaxed) != 0;
   int cap = ls.chunk_cap.load(std::memory_order_relaxed);
   cap = cap < 0 ? 0 : cap > 255 ? 255 : cap;
+  if (!static_part && cap == 0 && cu_limit <= 0 && n_tiles <= ls.tail_tiles.load(std::memory_order_relaxed))
+    return rfd_occ_tail_launch(n_tiles, pts, tile_prop, tile_src, packed, fc_p_w, table, fc_out_w, fc_out_b, logits,
+                               rfd_status_word(ws, s), lin, values, pstate, n_per, mode, s);
   int tiles_per_wg = ceil_div(n_tiles, ncu);
   int grid = static_part ? ceil_div(n_tiles, tiles_per_wg) : (n_tiles < ncu ? n_tiles : ncu);
   // the counter pair of THIS stream (serial launches: never shared with a launch in flight)

@@ -17,6 +17,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "tail: the test chooses the decoder's launch route itself (tests/test_gpu_decoder.py)")
 
 
 @pytest.fixture(scope="session")

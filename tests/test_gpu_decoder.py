@@ -13,6 +13,21 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-4
 
 
+@pytest.fixture(autouse=True)
+def main_kernel_only(request, hip):
+    """The kernel-level tests of this module are about occ_decode8_kernel: launches of any size stay on it.  Tests marked
+    `tail` choose the launch route themselves; the pipeline tests of the other modules run with the shipped default
+    (small launches on csrc/occ_decoder_tail.hip)."""
+    if request.node.get_closest_marker("tail"):
+        yield
+        return
+    old = hip.lib().rfd_occ_set_tail_tiles(0)
+    try:
+        yield
+    finally:
+        hip.lib().rfd_occ_set_tail_tiles(old)
+
+
 def seeded_decoder(seed=1234):
     from rfdnet_amd.iscnet.occ_decoder import DecoderCBatchNorm
     dec = DecoderCBatchNorm(dim=3, z_dim=32, c_dim=512, hidden_size=256)
@@ -281,6 +296,101 @@ def test_claimed_chunks_through_the_fused_scatter(hip):
     ok = lin >= 0
     got = outs[1][0][tp.repeat_interleave(128)[ok], lin[ok].long()]
     assert torch.equal(got, plain[ok])
+
+
+# ------------------------------------------------------------------ tail launches (round 6) ----
+@pytest.mark.tail
+@pytest.mark.parametrize("mode", ["x3", "x1"])
+def test_tail_kernel_is_bit_identical_to_the_main_kernel(hip, mode):
+    """csrc/occ_decoder_tail.hip (one wave per 16 points, no LDS, weights straight from L2) runs every accumulator through the
+    same sequence of matrix instructions as occ_decode8_kernel: identical logits, plain and through the fused MISE scatter,
+    with skipped tiles, with 16-slot groups that are all padding (skipped by the tail kernel, computed and dropped by the main
+    one), in both arithmetic modes; the f16-range flag is raised by both."""
+    from rfdnet_amd.iscnet import occ_decoder
+    lib = hip.lib()
+    dec = seeded_decoder(21)
+    if mode == "x1":
+        dec.mode = occ_decoder.MODE_F16X1
+    default = lib.rfd_occ_set_tail_tiles(-1)
+    assert default == 384
+    for K, skip in ((9, 0), (37, 5)):
+        pts, tile_prop, table, fcp = _ragged_launch(dec, K=K, seed=7 + K, skip_every=skip)
+        n_tiles = tile_prop.shape[0]
+        keep = (tile_prop >= 0).repeat_interleave(128)
+        try:
+            with torch.no_grad():
+                lib.rfd_occ_set_tail_tiles(0)
+                ref = dec.decode_tiles(pts, tile_prop, table, fcp)
+                lib.rfd_occ_set_tail_tiles(n_tiles)
+                got = dec.decode_tiles(pts, tile_prop, table, fcp)
+                lib.rfd_occ_set_tail_tiles(n_tiles - 1)           # one tile too many for the tail route: main kernel again
+                again = dec.decode_tiles(pts, tile_prop, table, fcp)
+        finally:
+            lib.rfd_occ_set_tail_tiles(default)
+        hip.device_status()
+        assert torch.equal(got[keep], ref[keep])
+        assert torch.equal(again[keep], ref[keep])
+        # through the scatter: most slots padding, whole 16-slot groups of padding, a few real points per tile
+        n = pts.shape[0]
+        tp_h = tile_prop.cpu().numpy()
+        rank = np.zeros(n_tiles, dtype=np.int64)                 # a tile's position among its proposal's (unskipped) tiles
+        seen = {}
+        for t, p_ in enumerate(tp_h):
+            if p_ >= 0:
+                rank[t] = seen.get(int(p_), 0)
+                seen[int(p_)] = rank[t] + 1
+        n_per = 128 * max(seen.values())
+        tp = tile_prop.long().clamp(min=0)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        real = torch.rand(n, device="cuda", generator=g) < 0.12
+        real &= ((torch.arange(n, device="cuda") // 16) % 3 != 1)          # every third group has no real slot at all
+        real &= keep
+        lin = (torch.from_numpy(rank).cuda().repeat_interleave(128) * 128 + torch.arange(n, device="cuda") % 128).int()
+        lin[~real] = -1
+        outs = []
+        for tail in (0, n_tiles):
+            values = torch.full((K, n_per), float("nan"), device="cuda")
+            pstate = torch.ones(K, n_per, dtype=torch.uint8, device="cuda")
+            lib.rfd_occ_set_tail_tiles(tail)
+            try:
+                with torch.no_grad():
+                    dec.decode_tiles(pts, tile_prop, table, fcp, scatter=(lin, values, pstate))
+            finally:
+                lib.rfd_occ_set_tail_tiles(default)
+            hip.device_status()
+            outs.append((values, pstate))
+        assert torch.equal(outs[0][1], outs[1][1])
+        known = outs[0][1] == 2
+        assert int(known.sum()) == int(real.sum()) > 0
+        assert torch.equal(outs[0][0][known], outs[1][0][known])
+        assert torch.equal(outs[1][0][tp.repeat_interleave(128)[real], lin[real].long()], ref[real])
+
+
+@pytest.mark.tail
+def test_tail_kernel_against_the_reference_fixture_and_range_flag(hip, golden_dir):
+    """F-DEC through the tail route (the fixture's launch is far below the default threshold), and the f16-range flag: the
+    tail kernel raises status bit 2 where the main kernel does (a table scaled out of the f16 range)."""
+    lib = hip.lib()
+    assert lib.rfd_occ_set_tail_tiles(-1) == 384
+    fx = np.load(os.path.join(golden_dir, "F_DEC.npz"))
+    dec = seeded_decoder(int(fx["seed"]))
+    with torch.no_grad():
+        out = dec(torch.from_numpy(fx["p"]).cuda(), torch.from_numpy(fx["z"]).cuda(),
+                  torch.from_numpy(fx["c"]).cuda())
+    hip.device_status()
+    assert np.abs(out.cpu().numpy() - fx["logits"]).max() < 2e-5
+    pts, tile_prop, table, fcp = _ragged_launch(dec, K=3, seed=2)
+    flags = []
+    for tail in (0, 384):
+        lib.rfd_occ_set_tail_tiles(tail)
+        try:
+            with torch.no_grad():
+                dec.decode_tiles(pts, tile_prop, (table * 4096.0).contiguous(), fcp)
+            torch.cuda.synchronize()
+            flags.append(hip.stream_status_bits())
+        finally:
+            lib.rfd_occ_set_tail_tiles(384)
+    assert flags[0] == flags[1] and flags[0] & 2, flags
 
 
 # ------------------------------------------------------------------ logit bands (round 4) ----

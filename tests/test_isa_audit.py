@@ -14,6 +14,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rfdnet_amd.build import CODEGEN_FLAGS  # noqa: E402  (the library's own code-generation flags)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
@@ -21,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_row_owner_gemm_has_no_use_before_landed(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     asm = str(tmp_path / "gemm.s")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+    subprocess.run([hipcc] + CODEGEN_FLAGS + [
                     "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "rfdnet_amd", "csrc"),
                     "-S", "--cuda-device-only", "-o", asm,
                     os.path.join(ROOT, "rfdnet_amd", "csrc", "gemm_f16x3.hip")],
@@ -46,7 +48,7 @@ def _asm(tmp_path, src, name, extra=()):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     asm = str(tmp_path / name)
     path = src if os.path.isabs(src) else os.path.join(ROOT, "rfdnet_amd", "csrc", src)
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+    subprocess.run([hipcc] + CODEGEN_FLAGS + [
                     "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "rfdnet_amd", "csrc"),
                     "-S", "--cuda-device-only", "-o", asm, path] + list(extra),
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path))
@@ -188,3 +190,37 @@ def test_no_two_wave_kernel_runs_a_valu_prologue_on_lds_reads_into_mfma_code_wit
     assert len(found) >= 64, (st, len(found))
     report.append("control (decoder tile prologue without its barrier): %d consumers flagged" % len(found))
     print("\n".join(report))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
+                    reason="hipcc not available")
+def test_no_kernel_contains_packed_fp32_with_op_sel(tmp_path):
+    """gfx950: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with an `op_sel` bit set (a source read from the HIGH half of its
+    register pair for the low result) return wrong values in lanes 48-63 while another wave of the SIMD executes matrix
+    instructions (tools/hazard/pk_f32_under_mfma.hip, profiles/r06_pk_f32_hazard.txt) -- round 2's wrong 16-point groups.  Any
+    kernel can end up beside a matrix kernel's waves, so none may contain the form: every source of the library is compiled
+    with the library's flags (rfdnet_amd/build.py: -fno-slp-vectorize keeps hipcc from forming them) and its assembly
+    scanned.  The positive control: the same scan finds them in the decoder's prologue as soon as the flag is dropped."""
+    import glob
+    import re
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_pk_f32
+    srcs = sorted(glob.glob(os.path.join(ROOT, "rfdnet_amd", "csrc", "*.hip")))
+    assert len(srcs) >= 18
+    with ThreadPoolExecutor(4) as ex:
+        asms = list(ex.map(lambda s: _asm(tmp_path, s, os.path.basename(s)[:-4] + ".s"), srcs))
+    kernels = 0
+    for a in asms:
+        found, n_kernels = audit_pk_f32.audit(a)
+        kernels += n_kernels
+        assert found == [], (os.path.basename(a), found[:3])
+    assert kernels >= 60, kernels
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    ctl = str(tmp_path / "control.s")
+    subprocess.run([hipcc] + [f for f in CODEGEN_FLAGS if f != "-fno-slp-vectorize"] +
+                   ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "rfdnet_amd", "csrc"), "-S",
+                    "--cuda-device-only", "-o", ctl, os.path.join(ROOT, "rfdnet_amd", "csrc", "occ_decoder8.hip")],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path))
+    found, _ = audit_pk_f32.audit(ctl)
+    assert len(found) >= 8 and any("occ_decode8_kernel" in k for k, _, _ in found), len(found)
