@@ -70,7 +70,9 @@ def main():
         del sys.argv[i:i + 2]
     d, n_points = sys.argv[1], float(sys.argv[2])
     tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
-    kern = "occ_decode8" if first else "occ_decode"
+    # the scenes' launches: the main kernel (occ_decode8_kernel) and, for rounds of <= 384 tiles, the tail kernel
+    # (occ_decode_tail_kernel) -- both match; the four-wave kernel (occ_decode_kernel) is not launched by bench.py
+    kern = "occ_decode"
     if first:
         f_rows = collect_rows(os.path.join(d, "fetch"), "FETCH_SIZE", kern)[:first]
         w_rows = collect_rows(os.path.join(d, "write"), "WRITE_SIZE", kern)[:first]
