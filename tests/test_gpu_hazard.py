@@ -1,0 +1,41 @@
+"""GPU (-m gpu): the stand-alone probe behind rfdnet_amd/build.py's -fno-slp-vectorize (tools/hazard/pk_f32_under_mfma.hip).
+
+What the library relies on is asserted: the forms it still contains -- scalar v_fma_f32, packed fp32 WITHOUT op_sel, op_sel_hi alone,
+v_pk_mov_b32 -- are exact beside another wave's matrix instructions, and every form is exact when the SIMD's other wave idles.  What
+round 6 found is reported and bounded: packed fp32 WITH an op_sel bit comes out wrong beside a partner's v_mfma chain, and then only in
+lanes 48-63 (profiles/r06_pk_f32_hazard.txt).  A box on which the hazard does not show is not a failure -- the flag costs nothing."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_packed_fp32_probe(hip, tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    exe = str(tmp_path / "pk_f32_under_mfma")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-w", "-o", exe,
+                    os.path.join(ROOT, "tools", "hazard", "pk_f32_under_mfma.hip")], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe, "20000"], check=True, capture_output=True, text=True, timeout=120).stdout
+    rows = []
+    for line in out.splitlines():
+        m = re.match(r"(.*?)\s+partner (MFMA|idle):\s+(\d+) waves, wrong\s+(\d+), wrong lanes by quarter \[(\d+) (\d+) (\d+) (\d+)\]", line)
+        if m:
+            rows.append((m.group(1).strip(), m.group(2), int(m.group(4)), [int(m.group(i)) for i in range(5, 9)]))
+    assert len(rows) == 9, out
+    affected = 0
+    for form, partner, wrong, quarters in rows:
+        packed_op_sel = re.search(r"v_pk_(fma|mul|add)_f32 op_sel:\[", form) is not None
+        if partner == "idle" or not packed_op_sel:
+            assert wrong == 0, (form, partner, wrong)           # the controls, and every form the library still contains
+        else:
+            assert quarters[:3] == [0, 0, 0], (form, quarters)  # if wrong at all, then in lanes 48-63 only
+            affected += wrong > 0
+    print("packed fp32 with op_sel beside a partner's MFMA chain: %d of 4 forms wrong on this box\n%s" % (affected, out))
