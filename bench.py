@@ -1070,6 +1070,13 @@ def main(argv=None):
                          "note": "algorithmic FLOPs (1 312 768 per query point) over HIP-event time of the decoder "
                                  "launches inside the timed region; f16x3 issues 3x that on the MFMA pipe"},
         }
+        if be.name != "stub":
+            from rfdnet_amd import _lib as _rfd_lib
+            out["roofline"]["tail_route"] = {
+                "max_tiles": int(_rfd_lib.lib().rfd_occ_set_tail_tiles(-1)),
+                "note": "decoder launches of at most max_tiles tiles (the last MISE rounds) run on occ_decode_tail_kernel "
+                        "(csrc/occ_decoder_tail.hip: one wave per 16 points, no LDS, logits bit-identical); they are inside "
+                        "`achieved` and `per_round` like every other decoder launch"}
         busy, busy_src = mfma_busy(args.mode)
         out["roofline"]["mfma_busy"] = busy
         out["roofline"]["mfma_busy_source"] = busy_src
