@@ -2,6 +2,9 @@
 # the round 1-5 flags): tail-kernel bit identity, the frozen decoder's rate, the encoder GEMMs, the headline -- one box, interleaved.
 #   bash tools/ab/r06_slp.sh   -> gpurun_out/r6slp/*
 O=$PWD/gpurun_out/r6slp; mkdir -p $O; V=$PWD/rfdnet_amd/lib/variants/librfd_slp.so
+# the control library: today's sources with the flags of rounds 1-5 (built here when it did not travel with the snapshot)
+if [ ! -f $V ]; then mkdir -p $(dirname $V); /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -Iinclude -o $V rfdnet_amd/csrc/*.hip || exit 1; fi
+[ -x tools/hazard/pk_f32_under_mfma ] || bash tools/hazard/build.sh || exit 1
 python tools/hazard/tail_vs_main.py 2>&1 | grep "mode\|tail\|more\|determinism" > $O/diag_new.txt; cat $O/diag_new.txt
 RFD_HIP_LIB=$V python tools/hazard/tail_vs_main.py 2>&1 | grep "mode\|tail\|more\|determinism" > $O/diag_slp.txt; cat $O/diag_slp.txt
 tools/hazard/pk_f32_under_mfma 50000 > $O/pk_f32_under_mfma.txt 2>&1
