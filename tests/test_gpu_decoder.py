@@ -393,6 +393,43 @@ def test_tail_kernel_against_the_reference_fixture_and_range_flag(hip, golden_di
     assert flags[0] == flags[1] and flags[0] & 2, flags
 
 
+@pytest.mark.tail
+def test_tail_kernel_beside_other_matrix_kernels(hip):
+    """The tail kernel's waves share SIMDs with whatever else runs (that is its point).  Beside a stream of library GEMMs
+    (MFMA kernels of a few workgroups: partner waves on the same SIMDs) and of elementwise passes its logits stay
+    bit-identical to the main kernel's, launch after launch -- the situation in which the first build, with hipcc's packed
+    fp32 op_sel forms in its prologue, went wrong (profiles/r06_pk_f32_hazard.txt)."""
+    lib = hip.lib()
+    dec = seeded_decoder(31)
+    pts, tile_prop, table, fcp = _ragged_launch(dec, K=9, seed=21)
+    n_tiles = tile_prop.shape[0]
+    default = lib.rfd_occ_set_tail_tiles(-1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(192, 1024, device="cuda", generator=g)
+    b = torch.randn(1024, 256, device="cuda", generator=g)
+    big = torch.empty(8 << 20, device="cuda")
+    side = torch.cuda.Stream()
+    try:
+        with torch.no_grad():
+            lib.rfd_occ_set_tail_tiles(0)
+            ref = dec.decode_tiles(pts, tile_prop, table, fcp)
+            torch.cuda.synchronize()
+            lib.rfd_occ_set_tail_tiles(n_tiles)
+            bad = 0
+            for it in range(25):
+                with torch.cuda.stream(side):
+                    for _ in range(40):                      # ~1 ms of small MFMA kernels and HBM passes beside the launch
+                        torch.mm(a, b)
+                        big.mul_(1.0001)
+                got = dec.decode_tiles(pts, tile_prop, table, fcp)
+                torch.cuda.synchronize()
+                bad += int((got != ref).sum())
+    finally:
+        lib.rfd_occ_set_tail_tiles(default)
+    hip.device_status()
+    assert bad == 0, bad
+
+
 # ------------------------------------------------------------------ logit bands (round 4) ----
 BANDS = [  # (name, conditioning scale, fc_out scale, absolute tolerance or None)
     ("+-3 (fc_out x4)", 1.0, 4.0, LOGIT_TOL),

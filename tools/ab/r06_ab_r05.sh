@@ -1,5 +1,7 @@
 # round-5 HEAD (337100b, a git worktree under .r05tree/) against this tree on ONE box, alternating: the boxes differ by
-# ~3 % in decoder speed, so only a same-box comparison says what round 6 changed
+# ~3 % in decoder speed, so only a same-box comparison says what round 6 changed.
+# Set-up (here, before the gpurun call): git worktree add .r05tree 337100b && (cd .r05tree && python -m rfdnet_amd.build);
+# afterwards: git worktree remove .r05tree --force   (the directory is git-ignored but travels with the snapshot)
 O=$PWD/gpurun_out/r6ab; mkdir -p $O; R=$PWD
 for i in 1 2 3; do
 (cd $R/.r05tree && timeout 200 python bench.py --no-cpu-baseline --no-extras --steps 16 --warmup 4 > $O/r05_$i.json 2>/dev/null)
