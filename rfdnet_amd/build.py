@@ -38,7 +38,8 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h")) + \
+        [os.path.abspath(__file__)]                     # the flags live in this file
     return any(os.path.getmtime(d) > t for d in deps)
 
 
