@@ -1,8 +1,8 @@
 """GPU (-m gpu): the stand-alone probe behind rfdnet_amd/build.py's -fno-slp-vectorize (tools/hazard/pk_f32_under_mfma.hip).
 
-What the library relies on is asserted: the forms it still contains -- scalar v_fma_f32, packed fp32 WITHOUT op_sel, op_sel_hi alone,
-v_pk_mov_b32 -- are exact beside another wave's matrix instructions, and every form is exact when the SIMD's other wave idles.  What
-round 6 found is reported and bounded: packed fp32 WITH an op_sel bit comes out wrong beside a partner's v_mfma chain, and then only in
+Asserted: every form is exact when the SIMD's other wave idles (the probe's own sanity).  Reported: the forms the library still contains
+-- scalar v_fma_f32, packed fp32 WITHOUT op_sel, op_sel_hi alone, v_pk_mov_b32 -- beside another wave's matrix instructions (exact on every
+box so far; a warning otherwise, the parity tests decide about the library).  What round 6 found is reported and bounded: packed fp32 WITH an op_sel bit comes out wrong beside a partner's v_mfma chain, and then only in
 lanes 48-63 (profiles/r06_pk_f32_hazard.txt).  A box on which the hazard does not show is not a failure -- the flag costs nothing."""
 import os
 import re
@@ -33,8 +33,14 @@ def test_packed_fp32_probe(hip, tmp_path):
     affected = 0
     for form, partner, wrong, quarters in rows:
         packed_op_sel = re.search(r"v_pk_(fma|mul|add)_f32 op_sel:\[", form) is not None
-        if partner == "idle" or not packed_op_sel:
-            assert wrong == 0, (form, partner, wrong)           # the controls, and every form the library still contains
+        if partner == "idle":
+            assert wrong == 0, (form, partner, wrong)           # nothing beside the reader: plain arithmetic, must be exact
+        elif not packed_op_sel:
+            # the forms the library still contains.  Exact on every box of rounds 6's pool; a box where they are not is reported,
+            # loudly, but does not stop the suite: the parity tests behind this one are what decides about the library
+            if wrong:
+                import warnings
+                warnings.warn("UNEXPECTED on this box: %s is wrong beside a partner's MFMA chain (%d waves, quarters %s)" % (form, wrong, quarters))
         else:
             assert quarters[:3] == [0, 0, 0], (form, quarters)  # if wrong at all, then in lanes 48-63 only
             affected += wrong > 0
