@@ -1,7 +1,8 @@
 """GPU (-m gpu): the stand-alone probe behind rfdnet_amd/build.py's -fno-slp-vectorize (tools/hazard/pk_f32_under_mfma.hip).
 
 Asserted: every form is exact when the SIMD's other wave idles (the probe's own sanity).  Reported: the forms the library still contains
--- scalar v_fma_f32, packed fp32 WITHOUT op_sel, op_sel_hi alone, v_pk_mov_b32 -- beside another wave's matrix instructions (exact on every
+-- scalar v_fma_f32, packed fp32 WITHOUT op_sel, op_sel_hi alone, v_pk_mov_b32, and the 16-bit op_sel forms of the hi / lo split
+(v_fma_mix_f32, v_pk_fma_f16, v_pk_add_u16) -- beside another wave's matrix instructions (exact on every
 box so far; a warning otherwise, the parity tests decide about the library).  What round 6 found is reported and bounded: packed fp32 WITH an op_sel bit comes out wrong beside a partner's v_mfma chain, and then only in
 lanes 48-63 (profiles/r06_pk_f32_hazard.txt).  A box on which the hazard does not show is not a failure -- the flag costs nothing."""
 import os
@@ -29,7 +30,7 @@ def test_packed_fp32_probe(hip, tmp_path):
         m = re.match(r"(.*?)\s+partner (MFMA|idle):\s+(\d+) waves, wrong\s+(\d+), wrong lanes by quarter \[(\d+) (\d+) (\d+) (\d+)\]", line)
         if m:
             rows.append((m.group(1).strip(), m.group(2), int(m.group(4)), [int(m.group(i)) for i in range(5, 9)]))
-    assert len(rows) == 9, out
+    assert len(rows) == 12, out
     affected = 0
     for form, partner, wrong, quarters in rows:
         packed_op_sel = re.search(r"v_pk_(fma|mul|add)_f32 op_sel:\[", form) is not None
