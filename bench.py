@@ -925,6 +925,65 @@ def pointop_rooflines(device, pc):
     return fps, bq
 
 
+def encoder_gemm_roofline():
+    """The second-largest kernel of a scene, measured live like the two point ops: the ten GEMMs of the skip-propagation
+    encoder (ResnetPointnet, layers.py:340-392: 256 proposals x 1024 points = 262 144 rows; fc_0 512 x 1024|512, [fc_1 |
+    shortcut] 512 x 1536|1024; the last block's second GEMM only pools) on fragment-ordered split activations, at the
+    headline shapes with synthetic operands, HIP events on the launch stream.  `achieved` = ALGORITHMIC flop (2 M N K per
+    GEMM; the f16x3 scheme issues 3x that on the matrix pipe) over the ten launches' time."""
+    import torch
+    from rfdnet_amd import gemm
+    M, h, T = 262144, 512, 1024
+    sa = gemm.SA
+    g = torch.Generator(device="cuda").manual_seed(0)
+
+    def timed(fn, it=5):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / it
+
+    ms = flop = 0.0
+    per = {}
+    hb = h // 32
+    gb = torch.randn(M // T, h, device="cuda", generator=g)
+    pool = torch.zeros(M // T, h, device="cuda")
+    for name, kin, n_full, n_pool in (("block 0", 2 * h, 1, 0), ("blocks 1-4", h, 3, 1)):
+        w1 = torch.randn(h, kin, device="cuda", generator=g) * 0.05
+        w2 = torch.randn(h, h + kin, device="cuda", generator=g) * 0.05
+        rows = torch.randn(M, h + kin, device="cuda", generator=g)
+        fcat = gemm.rows_to_frag(rows, sa=sa)
+        fnxt = gemm.frag_empty(M, 2 * h, "cuda")
+        t1 = timed(lambda: gemm.linear_frag(fcat[:, hb:], w1, gbias=gb, rows_per_group=T, out=fcat[:, :hb], sa=sa))
+        fcat = gemm.rows_to_frag(rows, sa=sa)                           # fc_0 wrote into the hidden window: fresh operands for the second GEMM
+        del rows
+        t2 = timed(lambda: gemm.linear_frag(fcat, w2, gbias=gb, rows_per_group=T, out=fnxt[:, hb:], pool=pool, sa=sa))
+        t2p = timed(lambda: gemm.linear_frag(fcat, w2, gbias=gb, rows_per_group=T, pool=pool, store=False, sa=sa)) if n_pool else 0.0
+        fl1, fl2 = 2.0 * M * h * kin, 2.0 * M * h * (h + kin)
+        ms += (n_full + n_pool) * t1 + n_full * t2 + n_pool * t2p
+        flop += (n_full + n_pool) * fl1 + (n_full + n_pool) * fl2
+        per[name] = {"fc_0_ms": t1, "fc_1_shortcut_ms": t2, "fc_1_shortcut_pool_only_ms": t2p or None,
+                     "fc_0_tflops": fl1 / t1 / 1e9, "fc_1_shortcut_tflops": fl2 / t2 / 1e9}
+        del fcat, fnxt
+    _ = torch.cuda.current_stream().synchronize()
+    hip_status = None
+    try:
+        from rfdnet_amd import _lib
+        hip_status = int(_lib.stream_status_bits())       # synthetic operands may trip the f16-range flag: read and clear it
+    except Exception:
+        pass
+    ach = flop / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_rowsf_kernel (csrc/gemm_f16x3.hip), ten launches of one scene's encoder",
+            "ms_per_scene": ms, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+            "algorithmic_flop_per_scene": flop, "blocks": per, "status_bits_cleared": hip_status,
+            "note": "f16x3 split GEMMs: three matrix instructions per product, so 1/3 of the dense f16 peak is this scheme's ceiling"}
+
+
 def mfma_busy(mode):
     """matrix-pipe busy share of the decoder's SIMD time from the committed counter passes (rocprofv3 --pmc
     SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAVE_CYCLES over tools/dec_only.py; counters cannot be read from inside this
@@ -1110,6 +1169,10 @@ def main(argv=None):
             out["roofline_grouping"] = grouping_roofline(be.device)
         if be.name == "hip" and not args.no_extras:
             out["roofline_fps"], out["roofline_ball_query"] = pointop_rooflines(be.device, be.scenes[min(be.scenes)])
+            try:
+                out["roofline_encoder_gemm"] = encoder_gemm_roofline()
+            except Exception as e:                       # never let an extra take the line down
+                out["roofline_encoder_gemm"] = {"error": repr(e)}
         if single is not None:
             out["single_scene"] = {"scenes_in_flight": 1, "ms_per_scene": 1e3 * single,
                                    "scenes_per_s": 1.0 / single,

@@ -40,6 +40,18 @@ def test_stress_line_carries_both_arithmetic_modes_and_the_pipe_busy_figure(hip)
     assert x1["mfma_busy"] and x1["mfma_busy"] < r["mfma_busy"]
 
 
+def test_headline_line_carries_the_per_kernel_rooflines(hip):
+    """the extras of the default configuration: the two point ops, the encoder's GEMMs and the tail route, measured live"""
+    out = _bench("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency")
+    assert out["config"]["scenes_failed"] == 0 and out["roofline"]["tail_route"]["max_tiles"] == 384
+    rounds = out["roofline"]["per_round"]
+    assert len(rounds) == 3 and rounds[2]["avg_launch_ms"] < 1.5             # the 64^3 tail round runs on the tail kernel
+    g = out["roofline_encoder_gemm"]
+    assert "error" not in g, g
+    assert 4.0 < g["ms_per_scene"] < 8.0 and 0.12 < g["frac"] < 1.0 / 3 and g["status_bits_cleared"] == 0
+    assert 0.5 < out["roofline_fps"]["us_per_round"] < 5.0 and out["roofline_ball_query"]["frac"] > 0.01
+
+
 def test_demo_workload_line(hip):
     out = _bench("--config", "demo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras")
     c = out["config"]
