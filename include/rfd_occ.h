@@ -137,6 +137,19 @@ int rfd_mise_subdivide(int K, int res0, int depth, double threshold,
 int rfd_mise_subdivide_active(int K, int res0, int depth, double threshold, const float *values,
                               unsigned char *pstate, unsigned char *vstate, const int *evaluated,
                               void *stream);
+/* The same pass with dirty-slab bookkeeping, for octrees whose last rounds evaluate a few thousand points (generator.py:99-117:
+ * the loop runs until query() is empty, and every pass of the plain entry stages every slab that holds a leaf voxel).  A leaf
+ * can only split if a point of its closed cube has become known since the previous pass or if that pass created it, so:
+ * dirty_cur / dirty_next are two [K][rfd_mise_dirty_elems(res0, depth)] byte maps, zero before the first round and SWAPPED
+ * by the caller after every call; every call records the slabs of the voxels it creates in dirty_next and leaves dirty_cur
+ * zeroed.  use_dirty != 0: the n_slots query slots of the round just decoded (lin[slot] = lattice index, < 0 = padding;
+ * tile_prop[slot / 128] = proposal) are marked into dirty_cur first and clean slabs are skipped; use_dirty == 0: every slab
+ * is examined (lin / tile_prop are not read).  Results identical to rfd_mise_subdivide_active either way. */
+size_t rfd_mise_dirty_elems(int res0, int depth);           /* per proposal */
+int rfd_mise_subdivide_dirty(int K, int res0, int depth, double threshold, const float *values,
+                             unsigned char *pstate, unsigned char *vstate, const int *evaluated, long long n_slots,
+                             const int *lin, const int *tile_prop, unsigned char *dirty_cur,
+                             unsigned char *dirty_next, int use_dirty, void *stream);
 /* to_dense (mise.pyx:133-163): forward-fill along x, then y, then z.  pstate is working
  * storage here: its content after the call is unspecified (only `values` is the result). */
 int rfd_mise_to_dense(int K, int res0, int depth, float *values,

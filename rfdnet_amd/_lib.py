@@ -51,6 +51,7 @@ SIGNATURES = {
     "rfd_mise_scatter": [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f],
     "rfd_mise_subdivide": [_i, _i, _i, C.c_double, _f, _f, _f, _f],
     "rfd_mise_subdivide_active": [_i, _i, _i, C.c_double, _f, _f, _f, _f, _f],
+    "rfd_mise_subdivide_dirty": [_i, _i, _i, C.c_double, _f, _f, _f, _f, C.c_longlong, _f, _f, _f, _f, _i, _f],
     "rfd_mise_to_dense": [_i, _i, _i, _f, _f, _f],
     "rfd_points_in_boxes": [_i, _i, _i, _i, _f, _f, _f, _f],
     "rfd_nms3d": [_i, _i, C.c_double, _i, _i, _f, _f, _f, _f, _f, _f],
@@ -84,7 +85,7 @@ _RESTYPES = {
     "rfd_occ_packed_bytes": C.c_size_t,
 }
 _INT_FNS = {"rfd_stream_status": [_f], "rfd_release_stream": [_f], "rfd_stream_status_snapshot": [_f, _f]}
-_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_frag_bytes": [_i, _i], "rfd_chain_packed_bytes": [], "rfd_chain_packed_bytes_n": [_i], "rfd_head_packed_bytes": []}
+_SIZE_FNS = {"rfd_mise_vstate_elems": [_i, _i], "rfd_mise_dirty_elems": [_i, _i], "rfd_gemm_packed_bytes": [_i, _i], "rfd_frag_bytes": [_i, _i], "rfd_chain_packed_bytes": [], "rfd_chain_packed_bytes_n": [_i], "rfd_head_packed_bytes": []}
 
 _lib = None
 

@@ -245,13 +245,75 @@ __global__ void mise_scatter_kernel(size_t n_per, const int *__restrict__ tile_p
   pstate[(size_t)k * n_per + l] = 2;             // :102 known = True
 }
 
+// ---- dirty slabs (round 6) ----------------------------------------------------------------------------------
+// Whether a leaf voxel splits is a function of the KNOWN points of its closed cube.  After a pass no leaf it examined is
+// mixed (it would have been split), so in the next pass only two kinds of leaf can split: one whose cube holds a point
+// that has become known SINCE -- a query point of the round just decoded -- and one the previous pass CREATED (children
+// are not examined in the pass that creates them, mise.pyx:239-251).  The last rounds of an octree evaluate a few
+// thousand points, yet a pass stages every slab that holds a leaf: 2.6 ms per tail round at 128^3, 5 % of a scene.
+// A byte per (proposal, level, slab of the LDS kernel's decomposition): the query list of the round marks the slabs of
+// the (up to eight) voxels per level whose cube contains each point, a subdivision marks its children's slabs in the
+// buffer of the NEXT pass, and a pass told to (`use_dirty`: the caller does so for sparse rounds) skips clean slabs.
+// Results are identical by construction; tests/test_gpu_generator.py runs every pass of every case in this mode
+// against the octree oracle.
+constexpr int SUB_TJ = 8, SUB_TK = 32;
+
+__host__ __device__ inline int sub_tiles_k(int nl) { return (nl + SUB_TK - 1) / SUB_TK; }
+__host__ __device__ inline int sub_tiles_j(int nl) { return (nl + SUB_TJ - 1) / SUB_TJ; }
+__host__ __device__ inline size_t dirty_offset(int res0, int l) {
+  size_t o = 0;
+  for (int i = 0; i < l; ++i) {
+    const int nl = res0 << i;
+    o += (size_t)sub_tiles_k(nl) * sub_tiles_j(nl) * nl;
+  }
+  return o;
+}
+__device__ inline size_t dirty_tile(int nl, int vi, int vj, int vk) {
+  return ((size_t)vi * sub_tiles_j(nl) + vj / SUB_TJ) * sub_tiles_k(nl) + vk / SUB_TK;
+}
+// the eight children of voxel (vi, vj, vk) of level l live in two slabs of level l + 1 (2 vj and 2 vk are even: one j / k group)
+__device__ inline void mark_children(unsigned char *dirty_next, int res0, int l, int nl, int vi, int vj, int vk) {
+  unsigned char *d = dirty_next + dirty_offset(res0, l + 1);
+  d[dirty_tile(2 * nl, 2 * vi, 2 * vj, 2 * vk)] = 1;
+  d[dirty_tile(2 * nl, 2 * vi + 1, 2 * vj, 2 * vk)] = 1;
+}
+
+// one thread per query slot of the round just decoded
+__global__ void mise_mark_dirty_kernel(size_t n_slots, int R1, int res0, int depth, const int *__restrict__ lin,
+                                       const int *__restrict__ tile_prop, size_t d_per,
+                                       unsigned char *__restrict__ dirty) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  const int p = lin[i];
+  if (p < 0) return;
+  const int kp = tile_prop[i / RFD_OCC_TILE];
+  if (kp < 0) return;
+  const int c[3] = {p / (R1 * R1), (p / R1) % R1, p % R1};
+  unsigned char *dk = dirty + (size_t)kp * d_per;
+  for (int l = 0; l < depth; ++l) {
+    const int s = 1 << (depth - l), nl = res0 << l;
+    int v[3][2], n[3];
+    for (int a = 0; a < 3; ++a) {              // the voxels of this level whose closed interval holds c[a]
+      const int q = c[a] / s;
+      n[a] = 0;
+      if (q < nl) v[a][n[a]++] = q;
+      if (c[a] % s == 0 && q > 0) v[a][n[a]++] = q - 1;
+    }
+    unsigned char *d = dk + dirty_offset(res0, l);
+    for (int a = 0; a < n[0]; ++a)
+      for (int b = 0; b < n[1]; ++b)
+        for (int e = 0; e < n[2]; ++e) d[dirty_tile(nl, v[0][a], v[1][b], v[2][e])] = 1;
+  }
+}
+
 // One level of subdivide_voxels.  Thread per voxel of level `l`.
 __global__ void mise_subdivide_kernel(int R1, int res0, int depth, int l, double thr,
                                       size_t n_per, size_t v_per,
                                       const float *__restrict__ values,
                                       unsigned char *__restrict__ pstate,
                                       unsigned char *__restrict__ vstate,
-                                      const int *__restrict__ evaluated) {
+                                      const int *__restrict__ evaluated, size_t d_per,
+                                      unsigned char *__restrict__ dirty_next) {
   const int nl = res0 << l;
   const size_t nvox = cube((size_t)nl);
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +347,7 @@ __global__ void mise_subdivide_kernel(int R1, int res0, int depth, int l, double
       for (int b = 0; b < 2; ++b)
         for (int c = 0; c < 2; ++c)
           vc[((size_t)(2 * vi + a) * nc + (2 * vj + b)) * nc + (2 * vk + c)] = 1;
+    if (dirty_next) mark_children(dirty_next + (size_t)kp * d_per, res0, l, nl, vi, vj, vk);
   }
   const int h = s >> 1;
   for (int a = 0; a < 3; ++a)
@@ -300,12 +363,11 @@ __global__ void mise_subdivide_kernel(int R1, int res0, int depth, int l, double
 // are read once, coalesced along z, into one flag byte each (bit0: known && v >= thr,
 // bit1: known && v <= thr, bit2: known).  The thread-per-voxel version above re-reads every
 // point 8..27 times with a stride of s elements between lanes (3.0 ms for 256 x 32^3 voxels).
-constexpr int SUB_TJ = 8, SUB_TK = 32;
-
 __global__ __launch_bounds__(SUB_TJ * SUB_TK) void mise_subdivide_lds_kernel(
     int R1, int res0, int depth, int l, double thr, size_t n_per, size_t v_per, size_t total_bytes,
     const float *__restrict__ values, unsigned char *__restrict__ pstate,
-    unsigned char *__restrict__ vstate, const int *__restrict__ evaluated) {
+    unsigned char *__restrict__ vstate, const int *__restrict__ evaluated, size_t d_per,
+    const unsigned char *__restrict__ dirty_cur, unsigned char *__restrict__ dirty_next) {
   extern __shared__ unsigned char flags[];
   const int nl = res0 << l;
   const int s = 1 << (depth - l);
@@ -318,6 +380,9 @@ __global__ __launch_bounds__(SUB_TJ * SUB_TK) void mise_subdivide_lds_kernel(
   // as the previous subdivision pass left them, and that pass found nothing more to split (it would have queued
   // points) -- the whole proposal is a no-op.  (The tail rounds of a deep octree touch a handful of proposals.)
   if (evaluated && evaluated[kp] == 0) return;
+  // A clean slab (no point of it has become known since the previous pass, no voxel of it was created by that pass) has
+  // nothing to decide (see "dirty slabs" above)
+  if (dirty_cur && dirty_cur[(size_t)kp * d_per + dirty_offset(res0, l) + tile] == 0) return;
   // A slab without a single leaf voxel of this level has nothing to decide either: skip it BEFORE its grid points are
   // staged.  At 128^3 the level-1 voxels exist only around the surface (~3 % of the 64^3 lattice), yet every round
   // staged all 869 M points of the level through the byte-granular path below: 27 ms per scene.
@@ -401,6 +466,7 @@ __global__ __launch_bounds__(SUB_TJ * SUB_TK) void mise_subdivide_lds_kernel(
       for (int b = 0; b < 2; ++b)
         for (int c = 0; c < 2; ++c)
           vc[((size_t)(2 * vi + a) * nc + (2 * vj + b)) * nc + (2 * vk + c)] = 1;
+    if (dirty_next) mark_children(dirty_next + (size_t)kp * d_per, res0, l, nl, vi, vj, vk);
   }
   const int h = s >> 1;
   for (int a = 0; a < 3; ++a)
@@ -600,11 +666,13 @@ RFD_API int rfd_mise_scatter(int n_tiles, int res0, int depth, const int *tile_p
 }
 
 static int mise_subdivide(int K, int res0, int depth, double threshold, const float *values,
-                          unsigned char *pstate, unsigned char *vstate, const int *evaluated, void *stream) {
+                          unsigned char *pstate, unsigned char *vstate, const int *evaluated, void *stream,
+                          const unsigned char *dirty_cur = nullptr, unsigned char *dirty_next = nullptr) {
   if (K <= 0 || depth <= 0) return 0;
   const int R1 = (res0 << depth) + 1;
   const size_t n_per = cube((size_t)R1);
   const size_t v_per = rfd_mise_vstate_elems(res0, depth);
+  const size_t d_per = dirty_offset(res0, depth);
   // fine -> coarse: children created at level l+1 were already visited this
   // round, so they cannot split until the next update (mise.pyx:239-251)
   for (int l = depth - 1; l >= 0; --l) {
@@ -615,13 +683,13 @@ static int mise_subdivide(int K, int res0, int depth, double threshold, const fl
       const size_t lds = (size_t)(sl + 1) * (SUB_TJ * sl + 1) * (SUB_TK * sl + 1);
       hipLaunchKernelGGL(mise_subdivide_lds_kernel, dim3(tiles, K), dim3(SUB_TJ * SUB_TK), lds,
                          (hipStream_t)stream, R1, res0, depth, l, threshold, n_per, v_per,
-                         n_per * (size_t)K, values, pstate, vstate, evaluated);
+                         n_per * (size_t)K, values, pstate, vstate, evaluated, d_per, dirty_cur, dirty_next);
       RFD_CHECK_LAUNCH();
       continue;
     }
     hipLaunchKernelGGL(mise_subdivide_kernel, dim3((unsigned)((nvox + 255) / 256), K), dim3(256), 0,
                        (hipStream_t)stream, R1, res0, depth, l, threshold, n_per, v_per, values,
-                       pstate, vstate, evaluated);
+                       pstate, vstate, evaluated, d_per, dirty_next);
     RFD_CHECK_LAUNCH();
   }
   return 0;
@@ -640,6 +708,38 @@ RFD_API int rfd_mise_subdivide_active(int K, int res0, int depth, double thresho
                                       const float *values, unsigned char *pstate,
                                       unsigned char *vstate, const int *evaluated, void *stream) {
   return mise_subdivide(K, res0, depth, threshold, values, pstate, vstate, evaluated, stream);
+}
+
+// Bytes of one proposal's dirty-slab map (see "dirty slabs" in the kernels' part of this file).
+RFD_API size_t rfd_mise_dirty_elems(int res0, int depth) { return dirty_offset(res0, depth); }
+
+// rfd_mise_subdivide_active with dirty-slab bookkeeping.  dirty_cur / dirty_next: two [K][rfd_mise_dirty_elems] byte maps,
+// zero before the first round, SWAPPED by the caller after every call.  Every call records the slabs of the voxels it
+// creates in dirty_next and leaves dirty_cur zeroed.  use_dirty != 0 (a round that evaluated few points): the n_slots query
+// slots of the round just decoded (lin[slot] = lattice index or < 0 for padding, tile_prop[slot / 128] = proposal) are marked
+// into dirty_cur first and the pass skips every clean slab; use_dirty == 0: the pass examines every slab as
+// rfd_mise_subdivide_active does (lin / tile_prop are not read).  Identical results either way.
+RFD_API int rfd_mise_subdivide_dirty(int K, int res0, int depth, double threshold, const float *values,
+                                     unsigned char *pstate, unsigned char *vstate, const int *evaluated,
+                                     long long n_slots, const int *lin, const int *tile_prop, unsigned char *dirty_cur,
+                                     unsigned char *dirty_next, int use_dirty, void *stream) {
+  if (K <= 0 || depth <= 0) return 0;
+  if (!dirty_cur || !dirty_next || (use_dirty && (!lin || !tile_prop || n_slots < 0))) {
+    rfd_set_error("rfd_mise_subdivide_dirty: dirty maps / query list", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  const int R1 = (res0 << depth) + 1;
+  const size_t d_per = dirty_offset(res0, depth);
+  if (use_dirty && n_slots > 0) {
+    hipLaunchKernelGGL(mise_mark_dirty_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (size_t)n_slots, R1, res0, depth, lin, tile_prop, d_per, dirty_cur);
+    RFD_CHECK_LAUNCH();
+  }
+  const int rc = mise_subdivide(K, res0, depth, threshold, values, pstate, vstate, evaluated, stream,
+                                use_dirty ? dirty_cur : nullptr, dirty_next);
+  if (rc) return rc;
+  RFD_CHECK(hipMemsetAsync(dirty_cur, 0, (size_t)K * d_per, (hipStream_t)stream));
+  return 0;
 }
 
 RFD_API int rfd_mise_to_dense(int K, int res0, int depth, float *values,

@@ -10,6 +10,8 @@ fused decode launch per MISE round over the concatenated query lists, the MISE
 state (values / point flags / octree flags) is dense and device-resident
 (csrc/mise.hip), and only K 4-byte counters per round cross PCIe.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -55,6 +57,9 @@ class Generator3D(object):
         self.simplify_nfaces = simplify_nfaces
         self.preprocessor = preprocessor
         self.use_cls_for_completion = use_cls_for_completion
+        # a MISE round that evaluated at most this many points per proposal on average runs its subdivision pass over the
+        # dirty slabs only (identical result; 0 = never)
+        self.sparse_round_points = int(os.environ.get('RFD_MISE_SPARSE_POINTS', 1024))     # (the variable: A/B runs only)
         self.stats = {}
 
     # ---- reference-shaped entry points ------------------------------------------
@@ -117,6 +122,8 @@ class Generator3D(object):
         pstate = torch.empty(K, n_per, dtype=torch.uint8, device=dev)
         vstate = torch.empty(K, v_per, dtype=torch.uint8, device=dev)
         counts = torch.empty(K, dtype=torch.int32, device=dev)
+        # dirty-slab maps of the subdivision passes (csrc/mise.hip "dirty slabs"): two, swapped every round
+        dirty = torch.zeros(2, K, lib.rfd_mise_dirty_elems(res0, depth), dtype=torch.uint8, device=dev)
         _call("rfd_mise_init", dev, K, res0, depth, pstate.data_ptr(), vstate.data_ptr())
         thr = self.logit_threshold()
         n_queries, rounds = 0, 0
@@ -159,8 +166,14 @@ class Generator3D(object):
                       logits.data_ptr(), values.data_ptr(), pstate.data_ptr())
             # proposals whose query was empty this round are finished (the reference's per-object loop has ended for
             # them, generator.py:104): the pass skips them; round 0 evaluates every proposal's lattice
-            _call("rfd_mise_subdivide_active", dev, K, res0, depth, float(thr), values.data_ptr(),
-                  pstate.data_ptr(), vstate.data_ptr(), None if shared else counts.data_ptr())
+            # a round that evaluated few points (the tail of the octree): only the slabs its points touch, and the ones the
+            # previous pass created voxels in, are examined -- identical result, a fraction of the lattice traffic
+            sparse = (not shared) and total <= K * self.sparse_round_points
+            _call("rfd_mise_subdivide_dirty", dev, K, res0, depth, float(thr), values.data_ptr(),
+                  pstate.data_ptr(), vstate.data_ptr(), None if shared else counts.data_ptr(),
+                  int(lin.numel()) if sparse else 0, lin.data_ptr() if sparse else None,
+                  tile_prop.data_ptr() if sparse else None, dirty[rounds & 1].data_ptr(),
+                  dirty[(rounds + 1) & 1].data_ptr(), int(sparse))
             n_queries += total
             per_round.append(total)
             rounds += 1

@@ -27,10 +27,11 @@ def gpu_mise(hip, fields, res0, depth, thr, active=False):
     pstate = torch.empty(K, n_per, dtype=torch.uint8, device=dev)
     vstate = torch.empty(K, lib.rfd_mise_vstate_elems(res0, depth), dtype=torch.uint8, device=dev)
     counts = torch.empty(K, dtype=torch.int32, device=dev)
+    dirty = torch.zeros(2, K, lib.rfd_mise_dirty_elems(res0, depth), dtype=torch.uint8, device=dev)
     st = hip.current_stream()
     hip.check(lib.rfd_mise_init(K, res0, depth, pstate.data_ptr(), vstate.data_ptr(), st), "init")
     per_round = []
-    for _ in range(64):
+    for rnd in range(64):
         hip.check(lib.rfd_mise_count(K, res0, depth, pstate.data_ptr(), counts.data_ptr(), st), "count")
         cnt = counts.cpu().numpy().astype(np.int64)
         if cnt.sum() == 0:
@@ -61,8 +62,17 @@ def gpu_mise(hip, fields, res0, depth, thr, active=False):
         hip.check(lib.rfd_mise_scatter(n_tiles, res0, depth, tile_prop.data_ptr(), None, lin.data_ptr(),
                                        torch.from_numpy(logits).cuda().data_ptr(), values.data_ptr(),
                                        pstate.data_ptr(), st), "scatter")
-        if active:
-            # the generator's entry point: a proposal whose query was empty this round is finished (the reference ends
+        if active == "dirty" or active == "mixed":
+            # the generator's entry point since round 6: dirty-slab bookkeeping; "dirty" = EVERY pass examines only the slabs
+            # the round's points touch or the previous pass created voxels in, "mixed" = alternating with full passes
+            use = 1 if active == "dirty" else rnd & 1
+            hip.check(lib.rfd_mise_subdivide_dirty(K, res0, depth, float(thr), values.data_ptr(), pstate.data_ptr(),
+                                                   vstate.data_ptr(), counts.data_ptr(), int(lin.numel()), lin.data_ptr(),
+                                                   tile_prop.data_ptr(), dirty[rnd & 1].data_ptr(),
+                                                   dirty[(rnd + 1) & 1].data_ptr(), use, st), "subdivide_dirty")
+            assert int(dirty[rnd & 1].sum()) == 0                  # the map just used comes back zeroed
+        elif active:
+            # the generator's entry point until round 5: a proposal whose query was empty this round is finished (the reference ends
             # that object's loop, generator.py:104) and is skipped; `counts` = what this round evaluated
             hip.check(lib.rfd_mise_subdivide_active(K, res0, depth, float(thr), values.data_ptr(), pstate.data_ptr(),
                                                     vstate.data_ptr(), counts.data_ptr(), st), "subdivide_active")
@@ -103,12 +113,13 @@ def plane_on_threshold(p, R):   # exact zeros: exercises the non-strict >= / <= 
     return (p[:, 0] - R // 2).astype(np.float64)
 
 
-@pytest.mark.parametrize("active", [False, True])
+@pytest.mark.parametrize("active", [False, True, "dirty", "mixed"])
 @pytest.mark.parametrize("res0,depth", [(4, 1), (8, 2), (16, 1), (4, 3), (32, 1), (32, 2)])
 def test_batched_mise_equals_octree_oracle(hip, oracle, res0, depth, active):
     """(32, 1) = the headline 64^3; (32, 2) = the 128^3 sweep configuration (configs[4]).  active: through
     rfd_mise_subdivide_active, which skips the proposals that evaluated nothing this round (the six fields finish after
-    one to five rounds, so every round of the deeper cases has finished and unfinished proposals side by side)."""
+    one to five rounds, so every round of the deeper cases has finished and unfinished proposals side by side).  "dirty" /
+    "mixed": through rfd_mise_subdivide_dirty with every pass (every other pass) restricted to the dirty slabs."""
     fields = [sphere(0.35), two_blobs, thin_slab, plane_on_threshold,
               lambda p, R: -np.ones(p.shape[0]), sphere(0.2, (0.4, 0.55, 0.6))]
     dense, rounds = gpu_mise(hip, fields, res0, depth, 0.0, active=active)
